@@ -1,0 +1,172 @@
+/*
+ * mdx.h — C ABI of libmdx.so, the MI355X-native MD engine behind the pipeline's
+ * `gmx mdrun` stages.
+ *
+ * The reference pipeline has no in-process API: every stage is the process pair
+ *     gmx grompp -f F.mdp -c C.gro [-r R.gro] [-t T.cpt] -p P.top [-n N.ndx] -o O.tpr
+ *     gmx mdrun -v -deffnm PREFIX -ntmpi 1 -ntomp 4
+ * (/root/reference/Snakefile:705-707, 738-740, 311-315, 994-998;
+ *  /root/reference/scripts/run_smd_with_distance_monitoring.py:66-75, 89-99).
+ * This header is the boundary a host (the Python `gmx` shim in molecular-dynamics_amd/cli.py,
+ * or any FFI) binds instead: plain pointers and sizes, int return codes, no exceptions, no
+ * torch types. Each group of setters names the .mdp keys / topology sections whose GROMACS
+ * behaviour it replaces.
+ *
+ * Conventions: units nm, ps, amu, kJ/mol, e, K, bar. Arrays are host pointers unless the
+ * name ends in _device. Indices are 0-based. One handle = one HIP device + one stream; a
+ * handle is not thread-safe. All calls return MDX_OK (0) or a negative error code;
+ * mdx_last_error() gives the text.
+ */
+#ifndef MDX_H
+#define MDX_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mdx_system mdx_system;
+
+enum {
+    MDX_OK = 0,
+    MDX_ERR_ARG = -1,
+    MDX_ERR_HIP = -2,
+    MDX_ERR_STATE = -3,
+    MDX_ERR_OVERFLOW = -4,
+    MDX_ERR_UNSUPPORTED = -5
+};
+
+/* energy term indices for mdx_get_energies() */
+enum {
+    MDX_E_LJ = 0,        /* LJ (SR), potential-shifted */
+    MDX_E_COUL_SR,       /* Ewald real space, potential-shifted */
+    MDX_E_COUL_RECIP,    /* PME mesh */
+    MDX_E_COUL_EXCL,     /* excluded-pair correction + Ewald self term */
+    MDX_E_BOND,
+    MDX_E_ANGLE,
+    MDX_E_DIH,
+    MDX_E_LJ14,
+    MDX_E_COUL14,
+    MDX_E_POSRES,
+    MDX_E_PULL,
+    MDX_E_DISPCORR,
+    MDX_E_KIN,           /* leap-frog average of the two half-step kinetic energies */
+    MDX_E_POT,           /* sum of all potential terms */
+    MDX_E_TEMP,
+    MDX_E_PRES,          /* scalar pressure, bar */
+    MDX_E_VOLUME,
+    MDX_E_CONSERVED,     /* total energy minus thermostat/barostat work */
+    MDX_E_N
+};
+
+/* force-term selection bits for mdx_compute_forces() */
+enum {
+    MDX_F_NONBONDED = 1,  /* LJ + Ewald real space on the cluster pair list */
+    MDX_F_PME = 2,        /* PME mesh part */
+    MDX_F_EXCL = 4,       /* excluded-pair Ewald correction (+ self energy) */
+    MDX_F_BONDED = 8,     /* bonds, angles, dihedrals, 1-4 pairs */
+    MDX_F_POSRES = 16,
+    MDX_F_PULL = 32,
+    MDX_F_ALL = 63
+};
+
+int mdx_version(void);
+/* Text of the last error on this handle (or of the last failed mdx_create when sys==NULL). */
+const char *mdx_last_error(const mdx_system *sys);
+
+/* Create a system of natoms atoms on HIP device `device`. Fails (returns NULL) when no HIP
+ * device is usable: there is no CPU fallback. */
+mdx_system *mdx_create(int device, int natoms);
+void mdx_destroy(mdx_system *sys);
+
+/* ---- topology: what `gmx grompp` bakes into the .tpr from the .top/.itp files
+ * (/root/reference/scripts/create_complex_topology.py:65-122, fix_ligand_topology.py:29-96). */
+/* Per-atom mass, charge, Lorentz-Berthelot sigma/epsilon (AMBER comb-rule 2), molecule index
+ * and T-coupling group (`tc-grps`, /root/reference/mdp/production.mdp:32). */
+int mdx_set_atoms(mdx_system *sys, const float *mass, const float *charge, const float *sigma,
+                  const float *epsilon, const int *molid, const int *tc_group);
+/* Exclusions as CSR over atoms (`nrexcl`, `[ exclusions ]`, `[ settles ]` implied pairs). */
+int mdx_set_exclusions(mdx_system *sys, const int *excl_start, const int *excl_list);
+/* `[ bonds ]` funct 1: idx 2 ints each; params (b0, kb). */
+int mdx_set_bonds(mdx_system *sys, int n, const int *idx, const float *b0, const float *kb);
+/* `[ angles ]` funct 1: idx 3 ints each; theta0 in degrees. */
+int mdx_set_angles(mdx_system *sys, int n, const int *idx, const float *theta0_deg, const float *k);
+/* `[ dihedrals ]` funct 1/4/9 (periodic): idx 4 ints each. */
+int mdx_set_dihedrals(mdx_system *sys, int n, const int *idx, const float *phi0_deg, const float *k,
+                      const int *mult);
+/* `[ pairs ]` funct 1 with fudgeLJ/fudgeQQ already applied: c6, c12, qq (= fudgeQQ*qi*qj). */
+int mdx_set_pairs14(mdx_system *sys, int n, const int *idx, const float *c6, const float *c12,
+                    const float *qq);
+/* `[ position_restraints ]` under `define = -DPOSRES` (/root/reference/mdp/nvt_complex.mdp:2);
+ * ref = the `grompp -r` coordinates; refcoord_scaling 0 no / 1 all / 2 com
+ * (/root/reference/mdp/npt_complex.mdp:72). */
+int mdx_set_posres(mdx_system *sys, int n, const int *idx, const float *ref_xyz, const float *k_xyz,
+                   int refcoord_scaling);
+/* `[ settles ]` (tip3p.itp): triples (O,H,H). */
+int mdx_set_settles(mdx_system *sys, int n, const int *idx, float d_oh, float d_hh);
+/* `constraints = h-bonds`, `constraint_algorithm = lincs`, `lincs_order`, `lincs_iter`
+ * (/root/reference/mdp/production.mdp:16-19; pull_short.mdp:12-15). */
+int mdx_set_constraints(mdx_system *sys, int n, const int *idx, const float *length, int lincs_order,
+                        int lincs_iter);
+
+/* ---- run parameters (the .mdp contract) */
+/* `rcoulomb`/`rvdw` (equal), pair-list radius, Ewald beta from `ewald-rtol`, `nstlist`. */
+int mdx_set_nonbonded(mdx_system *sys, float rc, float rlist, float ewald_beta, int nstlist);
+/* `coulombtype = PME`, `pme_order = 4`, grid from `fourierspacing`. nx=0 disables the mesh. */
+int mdx_set_pme(mdx_system *sys, int nx, int ny, int nz, int order);
+/* `dt`, `nstcalcenergy`, `nstcomm`. */
+int mdx_set_integrator(mdx_system *sys, float dt, int nstcalcenergy, int nstcomm);
+/* `tcoupl = V-rescale`: per group ref_t, tau_t, degrees of freedom; `nsttcouple`; `ld-seed`.
+ * ngroups = 0 switches the thermostat off (NVE). */
+int mdx_set_tcoupl(mdx_system *sys, int ngroups, const double *ref_t, const double *tau_t,
+                   const double *ndf, int nsttcouple, unsigned long long seed);
+/* `pcoupl`: 0 no, 1 C-rescale, 2 Parrinello-Rahman; isotropic; `tau_p`, `ref_p`,
+ * `compressibility`, `nstpcouple` (/root/reference/mdp/production.mdp:36-40). */
+int mdx_set_pcoupl(mdx_system *sys, int kind, double tau_p, double ref_p, double compressibility,
+                   int nstpcouple);
+/* `DispCorr`: 0 no, 1 Ener, 2 EnerPres; c6_avg = <C6> over all atom pairs. */
+int mdx_set_dispcorr(mdx_system *sys, int mode, double c6_avg);
+/* `pull = yes`, one `distance` coordinate between two groups
+ * (/root/reference/mdp/pull_short.mdp:36-46). type 0 constant-force (force = -k along the
+ * distance), 1 umbrella (reference = init + rate*t). start!=0 adds the initial distance to init.
+ * pbcatom: index into each group of the PBC reference atom (-1 = number-wise middle atom). */
+int mdx_set_pull(mdx_system *sys, int n1, const int *group1, int n2, const int *group2, int pbcatom1,
+                 int pbcatom2, int type, double k, double rate, double init, int start,
+                 const int *dim_xyz, int nstout);
+
+/* ---- state */
+/* x, v: natoms*3 floats (v may be NULL = zero); box: 9 floats, rows a,b,c (lower triangular). */
+int mdx_set_state(mdx_system *sys, const float *x, const float *v, const float *box9);
+/* Same, from device pointers (e.g. torch-ROCm tensors); copied device-to-device on the
+ * handle's stream. box9 is a host pointer. */
+int mdx_set_state_device(mdx_system *sys, const void *x_device, const void *v_device, const float *box9);
+int mdx_get_state(mdx_system *sys, float *x, float *v, float *box9);
+long long mdx_get_step(const mdx_system *sys);
+
+/* ---- compute */
+/* Single-point forces and energies of the selected terms at the current positions (rebuilds
+ * the pair list). Results via mdx_get_forces / mdx_get_energies / mdx_get_virial. */
+int mdx_compute_forces(mdx_system *sys, unsigned terms);
+int mdx_get_forces(mdx_system *sys, float *f);          /* natoms*3 */
+int mdx_get_energies(mdx_system *sys, double *e);       /* MDX_E_N doubles, last energy step */
+int mdx_get_virial(mdx_system *sys, double *vir9, double *pres9);
+/* Advance nsteps leap-frog steps (replaces `gmx mdrun` for `integrator = md`). Enqueues work
+ * on the handle's stream and returns; any getter synchronises. */
+int mdx_step(mdx_system *sys, long long nsteps);
+int mdx_synchronize(mdx_system *sys);
+/* Pair-list statistics of the last search: [0] super-clusters, [1] j-cluster entries,
+ * [2] work units, [3] exclusion masks, [4] cluster pairs (set bits of the i-masks). */
+int mdx_get_list_stats(mdx_system *sys, long long *stats5);
+/* Energy frames recorded every nstcalcenergy steps since the last call: each frame is
+ * (step, time, MDX_E_N terms). Returns the number of frames copied (<= max_frames). */
+long long mdx_pop_energy_frames(mdx_system *sys, double *out, long long max_frames);
+/* Pull records (time, value, force, work) written every pull nstout steps since the last call.
+ * These are what PREFIX_pullx.xvg / PREFIX_pullf.xvg carry
+ * (/root/reference/scripts/analyze_smd_trajectory.py:18-37). */
+long long mdx_pop_pull_records(mdx_system *sys, double *out, long long max_records);
+/* Time the nonbonded kernel with HIP events on the handle's stream (bench only). */
+int mdx_enable_kernel_timing(mdx_system *sys, int on);
+int mdx_get_kernel_timing(mdx_system *sys, double *nb_ms_total, long long *nb_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,711 @@
+// C ABI of libmdx.so (declared in include/mdx.h) and the per-step launch sequence.
+#include "mdx_internal.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+static thread_local std::string g_create_err;
+
+#define ARG_CHECK(sys, cond, msg)                                   \
+    do {                                                            \
+        if (!(cond)) { (sys)->err = (msg); return MDX_ERR_ARG; }    \
+    } while (0)
+
+template <typename T>
+static int dev_alloc(mdx_system *s, T **p, size_t count)
+{
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (count == 0) count = 1;
+    MDX_CHECK(s, hipMalloc((void **)p, sizeof(T) * count));
+    return MDX_OK;
+}
+template <typename T>
+static int dev_upload(mdx_system *s, T **p, const std::vector<T> &h)
+{
+    int rc = dev_alloc(s, p, h.size());
+    if (rc) return rc;
+    if (!h.empty()) MDX_CHECK(s, hipMemcpy(*p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+    return MDX_OK;
+}
+
+extern "C" int mdx_version(void) { return 100; }
+
+extern "C" const char *mdx_last_error(const mdx_system *sys)
+{
+    return sys ? sys->err.c_str() : g_create_err.c_str();
+}
+
+static void host_box(const double *b, DevBox *out)
+{
+    for (int a = 0; a < 9; a++) out->h[a] = (float)b[a];
+    const double ia = 1.0 / b[0], ie = 1.0 / b[4], ii = 1.0 / b[8];
+    const double inv[9] = { ia, 0, 0, -b[3] * ia * ie, ie, 0, (b[3] * b[7] - b[4] * b[6]) * ia * ie * ii, -b[7] * ie * ii, ii };
+    for (int a = 0; a < 9; a++) out->inv[a] = (float)inv[a];
+    out->vol = (float)(b[0] * b[4] * b[8]);
+    for (int a = 0; a < 5; a++) out->pad[a] = 0.0f;
+}
+
+extern "C" mdx_system *mdx_create(int device, int natoms)
+{
+    if (natoms <= 0) { g_create_err = "natoms must be positive"; return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_create_err = "no HIP device available (libmdx has no CPU fallback)";
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) { g_create_err = "device index out of range"; return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return nullptr; }
+    mdx_system *s = new mdx_system();
+    s->device = device; s->n = natoms;
+    bool ok = hipStreamCreate(&s->stream) == hipSuccess;
+    const int n = natoms;
+    s->ncol_cap = n / 128 + 256;
+    s->npad = ((n + 63) / 64 + s->ncol_cap) * 64;
+    s->cj_cap = (n / 64 + 1) * 768 + 4096;
+    s->work_cap = s->cj_cap / 8 + 1024;
+    s->excl_cap = n + 1024;
+    auto A = [&](auto **p, size_t c) { ok = ok && (dev_alloc(s, p, c) == MDX_OK); };
+    A(&s->x, n); A(&s->xp, n); A(&s->v, n); A(&s->f, 3 * (size_t)n); A(&s->lj, n); A(&s->molid, n); A(&s->tcgrp, n);
+    A(&s->xq_s, s->npad); A(&s->lj_s, s->npad); A(&s->f_s, 3 * (size_t)s->npad); A(&s->perm, s->npad); A(&s->perm_src, s->npad);
+    A(&s->shift_s, s->npad); A(&s->molid_s, s->npad); A(&s->sorted_of, n);
+    A(&s->bb_lo, s->npad / 8); A(&s->bb_hi, s->npad / 8); A(&s->sbb_lo, s->npad / 64); A(&s->sbb_hi, s->npad / 64);
+    A(&s->col_count, s->ncol_cap + 1); A(&s->col_astart, s->ncol_cap + 1); A(&s->col_scstart, s->ncol_cap + 1); A(&s->col_atoms, n);
+    A(&s->atom_col, n); A(&s->atom_slot, n); A(&s->wrapped, n);
+    A(&s->cj, s->cj_cap); A(&s->work, s->work_cap); A(&s->exclmask, (size_t)s->excl_cap * 64);
+    A(&s->shift_ijk, MDX_MAX_SHIFTS); A(&s->shiftvec, MDX_MAX_SHIFTS);
+    A(&s->excl_start, n + 1); A(&s->excl_list, 1); A(&s->d_tc, 3 * MDX_MAX_TC);
+    A(&s->d, 1);
+    ok = ok && hipHostMalloc((void **)&s->h, sizeof(DevState), hipHostMallocDefault) == hipSuccess;
+    s->ener_log_cap = 8192;
+    ok = ok && hipHostMalloc((void **)&s->ener_log, sizeof(double) * MDX_E_N * s->ener_log_cap, hipHostMallocDefault) == hipSuccess;
+    if (!ok) {
+        g_create_err = "allocation failed: " + s->err;
+        mdx_destroy(s);
+        return nullptr;
+    }
+    memset(s->h, 0, sizeof(DevState));
+    (void)hipMemset(s->d, 0, sizeof(DevState));
+    (void)hipMemset(s->excl_start, 0, sizeof(int) * (n + 1));
+    (void)hipMemset(s->tcgrp, 0, sizeof(int) * n);
+    (void)hipMemset(s->f, 0, sizeof(float) * 3 * n);
+    (void)hipMemset(s->f_s, 0, sizeof(float) * 3 * s->npad);
+    (void)hipMemset(s->sorted_of, 0, sizeof(int) * n);
+    return s;
+}
+
+extern "C" void mdx_destroy(mdx_system *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    mdx_pme_free(s);
+    void *ptrs[] = { s->x, s->xp, s->v, s->f, s->lj, s->molid, s->tcgrp, s->excl_start, s->excl_list, s->excl_pairs, s->xq_s, s->lj_s,
+                     s->f_s, s->perm, s->perm_src, s->shift_s, s->molid_s, s->sorted_of, s->bb_lo, s->bb_hi, s->sbb_lo, s->sbb_hi,
+                     s->col_count, s->col_astart, s->col_scstart, s->col_atoms, s->atom_col, s->atom_slot, s->wrapped, s->cj, s->work,
+                     s->exclmask, s->shift_ijk, s->shiftvec, s->bond_ij, s->bond_p, s->angle_ijk, s->angle_p, s->dih_ijkl, s->dih_p,
+                     s->pair_ij, s->pair_p, s->posres_idx, s->posres_ref, s->posres_k, s->settle_idx, s->cons_ij, s->cons_len,
+                     s->comp_start, s->d_tc, s->pull_idx[0], s->pull_idx[1], s->d };
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (s->h) (void)hipHostFree(s->h);
+    if (s->ener_log) (void)hipHostFree(s->ener_log);
+    if (s->pull_log) (void)hipHostFree(s->pull_log);
+    for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+// ---------------------------------------------------------------- topology
+static HostAtoms &host_atoms(mdx_system *s) { return s->host_atoms; }
+
+extern "C" int mdx_set_atoms(mdx_system *s, const float *mass, const float *charge, const float *sigma, const float *epsilon,
+                             const int *molid, const int *tc_group)
+{
+    ARG_CHECK(s, mass && charge && sigma && epsilon && molid, "mdx_set_atoms: null pointer");
+    (void)hipSetDevice(s->device);
+    const int n = s->n;
+    HostAtoms &ha = host_atoms(s);
+    ha.q.assign(charge, charge + n);
+    ha.invm.resize(n);
+    std::vector<float2> lj(n);
+    s->q2sum = 0.0;
+    for (int i = 0; i < n; i++) {
+        ARG_CHECK(s, mass[i] >= 0.0f && epsilon[i] >= 0.0f && sigma[i] >= 0.0f, "mdx_set_atoms: negative mass/sigma/epsilon");
+        ha.invm[i] = mass[i] > 0.0f ? 1.0f / mass[i] : 0.0f;
+        lj[i] = make_float2(0.5f * sigma[i], 2.0f * sqrtf(epsilon[i]));
+        s->q2sum += (double)charge[i] * charge[i];
+        if (tc_group) ARG_CHECK(s, tc_group[i] >= 0 && tc_group[i] < MDX_MAX_TC, "mdx_set_atoms: tc_group out of range");
+    }
+    MDX_CHECK(s, hipMemcpy(s->lj, lj.data(), sizeof(float2) * n, hipMemcpyHostToDevice));
+    MDX_CHECK(s, hipMemcpy(s->molid, molid, sizeof(int) * n, hipMemcpyHostToDevice));
+    if (tc_group) MDX_CHECK(s, hipMemcpy(s->tcgrp, tc_group, sizeof(int) * n, hipMemcpyHostToDevice));
+    return MDX_OK;
+}
+
+extern "C" int mdx_set_exclusions(mdx_system *s, const int *es, const int *el)
+{
+    ARG_CHECK(s, es, "mdx_set_exclusions: null pointer");
+    (void)hipSetDevice(s->device);
+    const int n = s->n;
+    ARG_CHECK(s, es[0] == 0, "mdx_set_exclusions: excl_start[0] must be 0");
+    const int ne = es[n];
+    std::vector<int2> pairs;
+    for (int i = 0; i < n; i++) {
+        ARG_CHECK(s, es[i + 1] >= es[i], "mdx_set_exclusions: excl_start not monotone");
+        for (int k = es[i]; k < es[i + 1]; k++) {
+            ARG_CHECK(s, el[k] >= 0 && el[k] < n, "mdx_set_exclusions: index out of range");
+            if (el[k] > i) pairs.push_back(make_int2(i, el[k]));
+        }
+    }
+    MDX_CHECK(s, hipMemcpy(s->excl_start, es, sizeof(int) * (n + 1), hipMemcpyHostToDevice));
+    int rc = dev_alloc(s, &s->excl_list, (size_t)ne);
+    if (rc) return rc;
+    if (ne) MDX_CHECK(s, hipMemcpy(s->excl_list, el, sizeof(int) * ne, hipMemcpyHostToDevice));
+    s->n_excl_pairs = (int)pairs.size();
+    return dev_upload(s, &s->excl_pairs, pairs);
+}
+
+static int check_idx(mdx_system *s, int n, const int *idx, int per, const char *what)
+{
+    for (int k = 0; k < n * per; k++)
+        if (idx[k] < 0 || idx[k] >= s->n) { s->err = std::string(what) + ": atom index out of range"; return MDX_ERR_ARG; }
+    return MDX_OK;
+}
+
+extern "C" int mdx_set_bonds(mdx_system *s, int n, const int *idx, const float *b0, const float *kb)
+{
+    (void)hipSetDevice(s->device);
+    ARG_CHECK(s, n >= 0 && (n == 0 || (idx && b0 && kb)), "mdx_set_bonds: bad arguments");
+    int rc = check_idx(s, n, idx, 2, "mdx_set_bonds"); if (rc) return rc;
+    std::vector<int2> ij(n); std::vector<float2> p(n);
+    for (int k = 0; k < n; k++) { ij[k] = make_int2(idx[2 * k], idx[2 * k + 1]); p[k] = make_float2(b0[k], kb[k]); }
+    s->nbonds = n;
+    rc = dev_upload(s, &s->bond_ij, ij); if (rc) return rc;
+    return dev_upload(s, &s->bond_p, p);
+}
+
+extern "C" int mdx_set_angles(mdx_system *s, int n, const int *idx, const float *th0, const float *k)
+{
+    (void)hipSetDevice(s->device);
+    ARG_CHECK(s, n >= 0 && (n == 0 || (idx && th0 && k)), "mdx_set_angles: bad arguments");
+    int rc = check_idx(s, n, idx, 3, "mdx_set_angles"); if (rc) return rc;
+    std::vector<int4> ij(n); std::vector<float2> p(n);
+    for (int a = 0; a < n; a++) {
+        ij[a] = make_int4(idx[3 * a], idx[3 * a + 1], idx[3 * a + 2], 0);
+        p[a] = make_float2((float)(th0[a] * M_PI / 180.0), k[a]);
+    }
+    s->nangles = n;
+    rc = dev_upload(s, &s->angle_ijk, ij); if (rc) return rc;
+    return dev_upload(s, &s->angle_p, p);
+}
+
+extern "C" int mdx_set_dihedrals(mdx_system *s, int n, const int *idx, const float *phi0, const float *k, const int *mult)
+{
+    (void)hipSetDevice(s->device);
+    ARG_CHECK(s, n >= 0 && (n == 0 || (idx && phi0 && k && mult)), "mdx_set_dihedrals: bad arguments");
+    int rc = check_idx(s, n, idx, 4, "mdx_set_dihedrals"); if (rc) return rc;
+    std::vector<int4> ij(n); std::vector<float4> p(n);
+    for (int a = 0; a < n; a++) {
+        ij[a] = make_int4(idx[4 * a], idx[4 * a + 1], idx[4 * a + 2], idx[4 * a + 3]);
+        p[a] = make_float4((float)(phi0[a] * M_PI / 180.0), k[a], (float)mult[a], 0.0f);
+    }
+    s->ndih = n;
+    rc = dev_upload(s, &s->dih_ijkl, ij); if (rc) return rc;
+    return dev_upload(s, &s->dih_p, p);
+}
+
+extern "C" int mdx_set_pairs14(mdx_system *s, int n, const int *idx, const float *c6, const float *c12, const float *qq)
+{
+    (void)hipSetDevice(s->device);
+    ARG_CHECK(s, n >= 0 && (n == 0 || (idx && c6 && c12 && qq)), "mdx_set_pairs14: bad arguments");
+    int rc = check_idx(s, n, idx, 2, "mdx_set_pairs14"); if (rc) return rc;
+    std::vector<int2> ij(n); std::vector<float4> p(n);
+    for (int a = 0; a < n; a++) {
+        ij[a] = make_int2(idx[2 * a], idx[2 * a + 1]);
+        p[a] = make_float4(c6[a], c12[a], qq[a] * MDX_ONE_4PI_EPS0, 0.0f);
+    }
+    s->npairs = n;
+    rc = dev_upload(s, &s->pair_ij, ij); if (rc) return rc;
+    return dev_upload(s, &s->pair_p, p);
+}
+
+extern "C" int mdx_set_posres(mdx_system *s, int n, const int *idx, const float *ref, const float *k, int refcoord_scaling)
+{
+    (void)hipSetDevice(s->device);
+    ARG_CHECK(s, n >= 0 && (n == 0 || (idx && ref && k)), "mdx_set_posres: bad arguments");
+    ARG_CHECK(s, refcoord_scaling >= 0 && refcoord_scaling <= 2, "mdx_set_posres: refcoord_scaling must be 0, 1 or 2");
+    int rc = check_idx(s, n, idx, 1, "mdx_set_posres"); if (rc) return rc;
+    std::vector<int> id(idx, idx + n); std::vector<float4> r(n), kk(n);
+    for (int a = 0; a < n; a++) {
+        r[a] = make_float4(ref[3 * a], ref[3 * a + 1], ref[3 * a + 2], 0.0f);
+        kk[a] = make_float4(k[3 * a], k[3 * a + 1], k[3 * a + 2], 0.0f);
+    }
+    s->nposres = n; s->refcoord_scaling = refcoord_scaling;
+    rc = dev_upload(s, &s->posres_idx, id); if (rc) return rc;
+    rc = dev_upload(s, &s->posres_ref, r); if (rc) return rc;
+    return dev_upload(s, &s->posres_k, kk);
+}
+
+extern "C" int mdx_set_settles(mdx_system *s, int n, const int *idx, float doh, float dhh)
+{
+    (void)hipSetDevice(s->device);
+    ARG_CHECK(s, n >= 0 && (n == 0 || idx), "mdx_set_settles: bad arguments");
+    ARG_CHECK(s, n == 0 || (doh > 0 && dhh > 0 && dhh < 2 * doh), "mdx_set_settles: bad geometry");
+    int rc = check_idx(s, n, idx, 3, "mdx_set_settles"); if (rc) return rc;
+    std::vector<int4> t(n);
+    for (int a = 0; a < n; a++) t[a] = make_int4(idx[3 * a], idx[3 * a + 1], idx[3 * a + 2], 0);
+    s->nsettle = n; s->settle_doh = doh; s->settle_dhh = dhh;
+    return dev_upload(s, &s->settle_idx, t);
+}
+
+extern "C" int mdx_set_constraints(mdx_system *s, int n, const int *idx, const float *length, int order, int iter)
+{
+    (void)hipSetDevice(s->device);
+    ARG_CHECK(s, n >= 0 && (n == 0 || (idx && length)), "mdx_set_constraints: bad arguments");
+    ARG_CHECK(s, order >= 1 && order <= 12 && iter >= 0 && iter <= 8, "mdx_set_constraints: lincs_order/lincs_iter out of range");
+    int rc = check_idx(s, n, idx, 2, "mdx_set_constraints"); if (rc) return rc;
+    // connected components over shared atoms (union-find on constraints)
+    std::vector<int> parent(n);
+    std::iota(parent.begin(), parent.end(), 0);
+    auto find = [&](int a) { while (parent[a] != a) { parent[a] = parent[parent[a]]; a = parent[a]; } return a; };
+    std::vector<int> owner(s->n, -1);
+    for (int k = 0; k < n; k++)
+        for (int e = 0; e < 2; e++) {
+            const int a = idx[2 * k + e];
+            if (owner[a] < 0) owner[a] = k;
+            else parent[find(k)] = find(owner[a]);
+        }
+    std::vector<int> order_idx(n);
+    std::iota(order_idx.begin(), order_idx.end(), 0);
+    std::vector<int> root(n);
+    for (int k = 0; k < n; k++) root[k] = find(k);
+    std::stable_sort(order_idx.begin(), order_idx.end(), [&](int a, int b) { return root[a] < root[b]; });
+    std::vector<int2> cij(n); std::vector<float> cl(n); std::vector<int> cstart;
+    for (int k = 0; k < n; k++) {
+        const int c = order_idx[k];
+        if (k == 0 || root[c] != root[order_idx[k - 1]]) cstart.push_back(k);
+        cij[k] = make_int2(idx[2 * c], idx[2 * c + 1]); cl[k] = length[c];
+    }
+    cstart.push_back(n);
+    for (size_t c = 0; c + 1 < cstart.size(); c++)
+        if (cstart[c + 1] - cstart[c] > MDX_LINCS_MAXK) {
+            s->err = "mdx_set_constraints: a coupled constraint component exceeds 16 constraints (only h-bond style topologies are supported)";
+            return MDX_ERR_UNSUPPORTED;
+        }
+    s->ncons = n; s->ncomp = n ? (int)cstart.size() - 1 : 0; s->lincs_order = order; s->lincs_iter = iter;
+    rc = dev_upload(s, &s->cons_ij, cij); if (rc) return rc;
+    rc = dev_upload(s, &s->cons_len, cl); if (rc) return rc;
+    return dev_upload(s, &s->comp_start, cstart);
+}
+
+// ---------------------------------------------------------------- run parameters
+extern "C" int mdx_set_nonbonded(mdx_system *s, float rc, float rlist, float beta, int nstlist)
+{
+    ARG_CHECK(s, rc > 0 && rlist >= rc && beta >= 0 && nstlist >= 1, "mdx_set_nonbonded: need rc > 0, rlist >= rc, nstlist >= 1");
+    s->rc = rc; s->rlist = rlist; s->beta = beta; s->nstlist = nstlist;
+    s->steps_since_search = 1 << 30;
+    return MDX_OK;
+}
+
+extern "C" int mdx_set_pme(mdx_system *s, int nx, int ny, int nz, int order)
+{
+    (void)hipSetDevice(s->device);
+    if (nx <= 0) { s->K[0] = s->K[1] = s->K[2] = 0; mdx_pme_free(s); return MDX_OK; }
+    ARG_CHECK(s, order == 4, "mdx_set_pme: only pme_order = 4 is implemented");
+    ARG_CHECK(s, nx >= 8 && ny >= 8 && nz >= 8, "mdx_set_pme: grid dimensions must be >= 8");
+    s->K[0] = nx; s->K[1] = ny; s->K[2] = nz;
+    return mdx_pme_init(s);
+}
+
+extern "C" int mdx_set_integrator(mdx_system *s, float dt, int nstcalcenergy, int nstcomm)
+{
+    ARG_CHECK(s, dt > 0 && nstcalcenergy >= 0 && nstcomm >= 0, "mdx_set_integrator: bad arguments");
+    s->dt = dt; s->nstcalcenergy = nstcalcenergy; s->nstcomm = nstcomm;
+    return MDX_OK;
+}
+
+extern "C" int mdx_set_tcoupl(mdx_system *s, int ng, const double *ref_t, const double *tau_t, const double *ndf, int nsttcouple,
+                              unsigned long long seed)
+{
+    (void)hipSetDevice(s->device);
+    ARG_CHECK(s, ng >= 0 && ng <= MDX_MAX_TC, "mdx_set_tcoupl: at most 8 groups");
+    ARG_CHECK(s, nsttcouple >= 1, "mdx_set_tcoupl: nsttcouple must be >= 1");
+    s->ntc = ng; s->nsttcouple = nsttcouple; s->seed = seed;
+    double buf[3 * MDX_MAX_TC] = { 0 };
+    for (int g = 0; g < ng; g++) {
+        ARG_CHECK(s, ref_t && tau_t && ndf, "mdx_set_tcoupl: null pointer");
+        s->ref_t[g] = ref_t[g]; s->tau_t[g] = tau_t[g]; s->ndf[g] = ndf[g];
+        buf[g] = ref_t[g]; buf[MDX_MAX_TC + g] = tau_t[g]; buf[2 * MDX_MAX_TC + g] = ndf[g];
+    }
+    if (ng == 0 && ndf) s->ndf_total = ndf[0];
+    MDX_CHECK(s, hipMemcpy(s->d_tc, buf, sizeof(buf), hipMemcpyHostToDevice));
+    s->first_step = true;
+    return MDX_OK;
+}
+
+extern "C" int mdx_set_pcoupl(mdx_system *s, int kind, double tau_p, double ref_p, double compress, int nstpcouple)
+{
+    ARG_CHECK(s, kind >= 0 && kind <= 2, "mdx_set_pcoupl: kind must be 0 (no), 1 (C-rescale) or 2 (Parrinello-Rahman)");
+    ARG_CHECK(s, kind == 0 || (tau_p > 0 && compress > 0 && nstpcouple >= 1), "mdx_set_pcoupl: bad parameters");
+    s->pcoupl = kind; s->tau_p = tau_p; s->ref_p = ref_p; s->compress = compress; s->nstpcouple = nstpcouple > 0 ? nstpcouple : 10;
+    return MDX_OK;
+}
+
+extern "C" int mdx_set_dispcorr(mdx_system *s, int mode, double c6avg)
+{
+    ARG_CHECK(s, mode >= 0 && mode <= 2, "mdx_set_dispcorr: mode must be 0, 1 or 2");
+    s->dispcorr = mode; s->dispcorr_c6avg = c6avg;
+    return MDX_OK;
+}
+
+extern "C" int mdx_set_pull(mdx_system *s, int n1, const int *g1, int n2, const int *g2, int pbc1, int pbc2, int type, double k,
+                            double rate, double init, int start, const int *dim, int nstout)
+{
+    (void)hipSetDevice(s->device);
+    if (n1 == 0 && n2 == 0) { s->pull_on = 0; return MDX_OK; }
+    ARG_CHECK(s, n1 > 0 && n2 > 0 && g1 && g2, "mdx_set_pull: both groups must be non-empty");
+    ARG_CHECK(s, type == 0 || type == 1, "mdx_set_pull: type must be 0 (constant-force) or 1 (umbrella)");
+    ARG_CHECK(s, nstout >= 1, "mdx_set_pull: nstout must be >= 1");
+    int rc = check_idx(s, n1, g1, 1, "mdx_set_pull"); if (rc) return rc;
+    rc = check_idx(s, n2, g2, 1, "mdx_set_pull"); if (rc) return rc;
+    std::vector<int> a(g1, g1 + n1), b(g2, g2 + n2);
+    rc = dev_upload(s, &s->pull_idx[0], a); if (rc) return rc;
+    rc = dev_upload(s, &s->pull_idx[1], b); if (rc) return rc;
+    s->pull_n[0] = n1; s->pull_n[1] = n2;
+    s->pull_pbcatom[0] = (pbc1 >= 0 && pbc1 < n1) ? pbc1 : (n1 - 1) / 2;
+    s->pull_pbcatom[1] = (pbc2 >= 0 && pbc2 < n2) ? pbc2 : (n2 - 1) / 2;
+    s->pull_type = type; s->pull_k = k; s->pull_rate = rate; s->pull_init_user = init; s->pull_start = start;
+    for (int d = 0; d < 3; d++) s->pull_dim[d] = dim ? dim[d] : 1;
+    s->pull_nstout = nstout;
+    if (!s->pull_log) {
+        s->pull_log_cap = 1 << 16;
+        MDX_CHECK(s, hipHostMalloc((void **)&s->pull_log, sizeof(double) * 4 * s->pull_log_cap, hipHostMallocMapped));
+    }
+    s->pull_log_count = 0;
+    s->pull_on = 1;
+    s->pull_reset_pending = true;
+    return MDX_OK;
+}
+
+// ---------------------------------------------------------------- state
+static int upload_box(mdx_system *s, const float *box9)
+{
+    ARG_CHECK(s, fabsf(box9[1]) + fabsf(box9[2]) + fabsf(box9[5]) < 1e-6f, "box must be lower triangular (a along x, b in the xy plane)");
+    ARG_CHECK(s, box9[0] > 0 && box9[4] > 0 && box9[8] > 0, "box diagonal must be positive");
+    for (int a = 0; a < 9; a++) s->h->boxd[a] = box9[a];
+    host_box(s->h->boxd, &s->h->box);
+    ARG_CHECK(s, box9[0] >= 2 * s->rlist * 0.999f && box9[4] >= 2 * s->rlist * 0.999f && box9[8] >= 2 * s->rlist * 0.999f,
+              "box diagonal shorter than twice the pair-list radius");
+    MDX_CHECK(s, hipMemcpyAsync(&s->d->box, &s->h->box, sizeof(DevBox), hipMemcpyHostToDevice, s->stream));
+    MDX_CHECK(s, hipMemcpyAsync(s->d->boxd, s->h->boxd, sizeof(double) * 9, hipMemcpyHostToDevice, s->stream));
+    MDX_CHECK(s, hipStreamSynchronize(s->stream));
+    return MDX_OK;
+}
+
+extern "C" int mdx_set_state(mdx_system *s, const float *x, const float *v, const float *box9)
+{
+    (void)hipSetDevice(s->device);
+    ARG_CHECK(s, x && box9, "mdx_set_state: null pointer");
+    HostAtoms &ha = host_atoms(s);
+    ARG_CHECK(s, (int)ha.q.size() == s->n, "mdx_set_state: call mdx_set_atoms first");
+    int rc = upload_box(s, box9); if (rc) return rc;
+    const int n = s->n;
+    std::vector<float4> hx(n), hv(n);
+    for (int i = 0; i < n; i++) {
+        hx[i] = make_float4(x[3 * i], x[3 * i + 1], x[3 * i + 2], ha.q[i]);
+        hv[i] = v ? make_float4(v[3 * i], v[3 * i + 1], v[3 * i + 2], ha.invm[i]) : make_float4(0, 0, 0, ha.invm[i]);
+        ARG_CHECK(s, std::isfinite(hx[i].x) && std::isfinite(hx[i].y) && std::isfinite(hx[i].z), "mdx_set_state: non-finite coordinate");
+    }
+    MDX_CHECK(s, hipMemcpy(s->x, hx.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    MDX_CHECK(s, hipMemcpy(s->v, hv.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    s->steps_since_search = 1 << 30; s->first_step = true; s->forces_current = false;
+    return MDX_OK;
+}
+
+__global__ void k_pack_state(int n, const float *__restrict__ x3, const float *__restrict__ v3, float4 *__restrict__ x, float4 *__restrict__ v)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 p = x[i]; p.x = x3[3 * i]; p.y = x3[3 * i + 1]; p.z = x3[3 * i + 2]; x[i] = p;
+    if (v3) { float4 w = v[i]; w.x = v3[3 * i]; w.y = v3[3 * i + 1]; w.z = v3[3 * i + 2]; v[i] = w; }
+}
+__global__ void k_set_qm(int n, const float *__restrict__ q, const float *__restrict__ im, float4 *__restrict__ x, float4 *__restrict__ v)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    x[i].w = q[i]; v[i].w = im[i];
+}
+__global__ void k_unpack_state(int n, const float4 *__restrict__ x, const float4 *__restrict__ v, float *__restrict__ x3, float *__restrict__ v3)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = x[i], w = v[i];
+    x3[3 * i] = p.x; x3[3 * i + 1] = p.y; x3[3 * i + 2] = p.z;
+    v3[3 * i] = w.x; v3[3 * i + 1] = w.y; v3[3 * i + 2] = w.z;
+}
+
+extern "C" int mdx_set_state_device(mdx_system *s, const void *xd, const void *vd, const float *box9)
+{
+    (void)hipSetDevice(s->device);
+    ARG_CHECK(s, xd && box9, "mdx_set_state_device: null pointer");
+    HostAtoms &ha = host_atoms(s);
+    ARG_CHECK(s, (int)ha.q.size() == s->n, "mdx_set_state_device: call mdx_set_atoms first");
+    int rc = upload_box(s, box9); if (rc) return rc;
+    const int n = s->n, nb = (n + 255) / 256;
+    // charges / inverse masses ride in the .w lanes: (re)write them from the host copies
+    float *tmp = nullptr;
+    MDX_CHECK(s, hipMalloc((void **)&tmp, sizeof(float) * 2 * n));
+    MDX_CHECK(s, hipMemcpy(tmp, ha.q.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+    MDX_CHECK(s, hipMemcpy(tmp + n, ha.invm.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_set_qm, dim3(nb), dim3(256), 0, s->stream, n, tmp, tmp + n, s->x, s->v);
+    if (!vd) MDX_CHECK(s, hipMemsetAsync(s->v, 0, sizeof(float4) * n, s->stream));
+    if (!vd) hipLaunchKernelGGL(k_set_qm, dim3(nb), dim3(256), 0, s->stream, n, tmp, tmp + n, s->x, s->v);
+    hipLaunchKernelGGL(k_pack_state, dim3(nb), dim3(256), 0, s->stream, n, (const float *)xd, (const float *)vd, s->x, s->v);
+    MDX_CHECK(s, hipStreamSynchronize(s->stream));
+    (void)hipFree(tmp);
+    s->steps_since_search = 1 << 30; s->first_step = true; s->forces_current = false;
+    return MDX_OK;
+}
+
+static int sync_and_check(mdx_system *s)
+{
+    MDX_CHECK(s, hipMemcpyAsync(s->h, s->d, sizeof(DevState), hipMemcpyDeviceToHost, s->stream));
+    MDX_CHECK(s, hipStreamSynchronize(s->stream));
+    if (s->h->overflow) {
+        s->err = "pair-list capacity exceeded (flags " + std::to_string(s->h->overflow) + "): 1 j-list, 2 work list, 4 masks, 8 column too tall, 16 clusters";
+        return MDX_ERR_OVERFLOW;
+    }
+    return MDX_OK;
+}
+
+extern "C" int mdx_synchronize(mdx_system *s)
+{
+    (void)hipSetDevice(s->device);
+    return sync_and_check(s);
+}
+
+extern "C" int mdx_get_state(mdx_system *s, float *x, float *v, float *box9)
+{
+    (void)hipSetDevice(s->device);
+    int rc = sync_and_check(s); if (rc) return rc;
+    const int n = s->n, nb = (n + 255) / 256;
+    float *tmp = nullptr;
+    MDX_CHECK(s, hipMalloc((void **)&tmp, sizeof(float) * 6 * n));
+    hipLaunchKernelGGL(k_unpack_state, dim3(nb), dim3(256), 0, s->stream, n, s->x, s->v, tmp, tmp + 3 * n);
+    if (x) MDX_CHECK(s, hipMemcpyAsync(x, tmp, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, s->stream));
+    if (v) MDX_CHECK(s, hipMemcpyAsync(v, tmp + 3 * n, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, s->stream));
+    MDX_CHECK(s, hipStreamSynchronize(s->stream));
+    (void)hipFree(tmp);
+    if (box9) for (int a = 0; a < 9; a++) box9[a] = (float)s->h->boxd[a];
+    return MDX_OK;
+}
+
+extern "C" long long mdx_get_step(const mdx_system *s) { return s->step; }
+
+// ---------------------------------------------------------------- compute
+static int record_energy_frame(mdx_system *s)
+{
+    const long long slot = s->ener_log_count % s->ener_log_cap;
+    MDX_CHECK(s, hipMemcpyAsync(s->ener_log + slot * MDX_E_N, s->d->ener, sizeof(double) * MDX_E_N, hipMemcpyDeviceToHost, s->stream));
+    s->ener_log_count++;
+    return MDX_OK;
+}
+
+static std::vector<long long> &frame_steps(mdx_system *s) { return s->frame_steps; }
+
+extern "C" int mdx_compute_forces(mdx_system *s, unsigned terms)
+{
+    (void)hipSetDevice(s->device);
+    int rc;
+    if ((rc = mdx_launch_clear(s, true, true, true))) return rc;
+    MDX_CHECK(s, hipMemsetAsync(s->f, 0, sizeof(float) * 3 * s->n, s->stream));
+    if ((rc = mdx_search(s))) return rc;
+    if ((rc = mdx_launch_prepare(s))) return rc;
+    if (terms & MDX_F_NONBONDED) if ((rc = mdx_launch_nonbonded(s, true))) return rc;
+    if (terms & MDX_F_PME) if ((rc = mdx_launch_pme(s, true))) return rc;
+    if ((rc = mdx_launch_bonded(s, true, terms))) return rc;
+    if (terms & MDX_F_PULL) if ((rc = mdx_launch_pull(s, false, true))) return rc;
+    if ((rc = mdx_launch_ke(s, true, true))) return rc;
+    if ((rc = mdx_launch_ke(s, false, true))) return rc;
+    if ((rc = mdx_launch_finish_energy(s))) return rc;
+    s->forces_current = true;
+    return sync_and_check(s);
+}
+
+extern "C" int mdx_get_forces(mdx_system *s, float *f)
+{
+    (void)hipSetDevice(s->device);
+    ARG_CHECK(s, f, "mdx_get_forces: null pointer");
+    ARG_CHECK(s, s->forces_current, "mdx_get_forces: no forces computed at the current positions");
+    float *tmp = nullptr;
+    MDX_CHECK(s, hipMalloc((void **)&tmp, sizeof(float) * 3 * s->n));
+    int rc = mdx_launch_merge_forces(s, tmp);
+    if (rc) { (void)hipFree(tmp); return rc; }
+    MDX_CHECK(s, hipMemcpyAsync(f, tmp, sizeof(float) * 3 * s->n, hipMemcpyDeviceToHost, s->stream));
+    MDX_CHECK(s, hipStreamSynchronize(s->stream));
+    (void)hipFree(tmp);
+    return MDX_OK;
+}
+
+extern "C" int mdx_get_energies(mdx_system *s, double *e)
+{
+    (void)hipSetDevice(s->device);
+    ARG_CHECK(s, e, "mdx_get_energies: null pointer");
+    int rc = sync_and_check(s); if (rc) return rc;
+    for (int k = 0; k < MDX_E_N; k++) e[k] = s->h->ener[k];
+    return MDX_OK;
+}
+
+extern "C" int mdx_get_virial(mdx_system *s, double *vir9, double *pres9)
+{
+    (void)hipSetDevice(s->device);
+    int rc = sync_and_check(s); if (rc) return rc;
+    if (vir9) for (int k = 0; k < 9; k++) vir9[k] = s->h->vir[k];
+    if (pres9) for (int k = 0; k < 9; k++) pres9[k] = s->h->pres[k];
+    return MDX_OK;
+}
+
+extern "C" int mdx_get_list_stats(mdx_system *s, long long *st)
+{
+    (void)hipSetDevice(s->device);
+    ARG_CHECK(s, st, "mdx_get_list_stats: null pointer");
+    int rc = sync_and_check(s); if (rc) return rc;
+    st[0] = s->h->nsc; st[1] = s->h->ncj; st[2] = s->h->nwork; st[3] = s->h->nexcl;
+    std::vector<NbEntry> e((size_t)std::max(0, std::min(s->h->ncj, s->cj_cap)));
+    if (!e.empty()) MDX_CHECK(s, hipMemcpy(e.data(), s->cj, sizeof(NbEntry) * e.size(), hipMemcpyDeviceToHost));
+    long long bits = 0;
+    for (const NbEntry &x : e) bits += __builtin_popcount(x.mask & 0xFFu);
+    st[4] = bits;
+    return MDX_OK;
+}
+
+static int drain_timing(mdx_system *s)
+{
+    if (s->ev_nb.empty()) return MDX_OK;
+    MDX_CHECK(s, hipStreamSynchronize(s->stream));
+    for (auto &p : s->ev_nb) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, s->ev_pool[p.first], s->ev_pool[p.second]) == hipSuccess) { s->nb_ms_total += ms; s->nb_launches++; }
+    }
+    for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
+    s->ev_pool.clear(); s->ev_nb.clear();
+    return MDX_OK;
+}
+
+extern "C" int mdx_enable_kernel_timing(mdx_system *s, int on)
+{
+    (void)hipSetDevice(s->device);
+    int rc = drain_timing(s); if (rc) return rc;
+    s->time_nb = on != 0; s->nb_ms_total = 0; s->nb_launches = 0;
+    return MDX_OK;
+}
+
+extern "C" int mdx_get_kernel_timing(mdx_system *s, double *ms, long long *launches)
+{
+    (void)hipSetDevice(s->device);
+    int rc = drain_timing(s); if (rc) return rc;
+    if (ms) *ms = s->nb_ms_total;
+    if (launches) *launches = s->nb_launches;
+    return MDX_OK;
+}
+
+extern "C" int mdx_step(mdx_system *s, long long nsteps)
+{
+    (void)hipSetDevice(s->device);
+    ARG_CHECK(s, nsteps >= 0, "mdx_step: nsteps must be >= 0");
+    int rc;
+    if (s->pull_on && s->pull_reset_pending) {
+        // the pull reference lives on the device; make sure the flag starts cleared
+        int zero = 0;
+        MDX_CHECK(s, hipMemcpyAsync(&s->d->pull_have_init, &zero, sizeof(int), hipMemcpyHostToDevice, s->stream));
+        MDX_CHECK(s, hipStreamSynchronize(s->stream));
+        s->pull_reset_pending = false;
+    }
+    for (long long it = 0; it < nsteps; it++) {
+        const long long step = s->step;
+        const bool do_search = s->steps_since_search >= s->nstlist;
+        const bool do_ener = s->nstcalcenergy > 0 && (step % s->nstcalcenergy == 0);
+        const bool do_pc = s->pcoupl != 0 && (step % s->nstpcouple == 0);
+        const bool need_vir = do_ener || do_pc;
+        const bool tc_apply = s->ntc > 0 && (step % s->nsttcouple == 0);
+        if (s->first_step && s->ntc > 0) {
+            if ((rc = mdx_launch_clear(s, false, true, false))) return rc;
+            if ((rc = mdx_launch_ke(s, false, false))) return rc;
+            if ((rc = mdx_launch_tcouple(s))) return rc;
+        }
+        s->first_step = false;
+        if (need_vir) {
+            if ((rc = mdx_launch_clear(s, true, true, true))) return rc;
+            if ((rc = mdx_launch_ke(s, true, true))) return rc;
+        }
+        MDX_CHECK(s, hipMemsetAsync(s->f, 0, sizeof(float) * 3 * s->n, s->stream));
+        if (do_search) if ((rc = mdx_search(s))) return rc;
+        if ((rc = mdx_launch_prepare(s))) return rc;
+        if ((rc = mdx_launch_nonbonded(s, need_vir))) return rc;
+        if ((rc = mdx_launch_pme(s, need_vir))) return rc;
+        if ((rc = mdx_launch_bonded(s, need_vir, MDX_F_BONDED | MDX_F_POSRES | (s->have_pme ? MDX_F_EXCL : 0)))) return rc;
+        if (s->pull_on) {
+            const bool log_now = (step % s->pull_nstout == 0);
+            if ((rc = mdx_launch_pull(s, log_now, need_vir))) return rc;
+        }
+        if ((rc = mdx_launch_update(s, tc_apply, s->pcoupl == 2, need_vir))) return rc;
+        if (need_vir) {
+            if ((rc = mdx_launch_ke(s, false, true))) return rc;
+            if ((rc = mdx_launch_finish_energy(s))) return rc;
+            if (do_ener) {
+                if ((rc = record_energy_frame(s))) return rc;
+                frame_steps(s).push_back(step);
+            }
+        }
+        if (do_pc) if ((rc = mdx_launch_pcouple(s))) return rc;
+        if (s->ntc > 0 && ((step + 1) % s->nsttcouple == 0)) {
+            if (!need_vir) {
+                if ((rc = mdx_launch_clear(s, false, true, false))) return rc;
+                if ((rc = mdx_launch_ke(s, false, false))) return rc;
+            }
+            if ((rc = mdx_launch_tcouple(s))) return rc;
+        }
+        if (s->nstcomm > 0 && ((step + 1) % s->nstcomm == 0)) if ((rc = mdx_launch_comm(s))) return rc;
+        s->step++;
+        s->steps_since_search++;
+        s->forces_current = false;
+        if (s->time_nb && s->ev_pool.size() > 8192) if ((rc = drain_timing(s))) return rc;
+    }
+    return MDX_OK;
+}
+
+extern "C" long long mdx_pop_energy_frames(mdx_system *s, double *out, long long max_frames)
+{
+    (void)hipSetDevice(s->device);
+    if (sync_and_check(s) != MDX_OK) return -1;
+    std::vector<long long> &steps = frame_steps(s);
+    const long long have = (long long)steps.size();
+    const long long avail = std::min<long long>(have, s->ener_log_cap);
+    const long long ncopy = std::min(avail, max_frames);
+    // frames are in the ring at indices (count - have ... count - 1); return the newest `ncopy` in order
+    for (long long k = 0; k < ncopy; k++) {
+        const long long fi = s->ener_log_count - ncopy + k;
+        const long long slot = fi % s->ener_log_cap;
+        const long long st = steps[(size_t)(have - ncopy + k)];
+        double *o = out + k * (2 + MDX_E_N);
+        o[0] = (double)st; o[1] = (double)st * s->dt;
+        memcpy(o + 2, s->ener_log + slot * MDX_E_N, sizeof(double) * MDX_E_N);
+    }
+    steps.clear();
+    return ncopy;
+}
+
+extern "C" long long mdx_pop_pull_records(mdx_system *s, double *out, long long max_records)
+{
+    (void)hipSetDevice(s->device);
+    if (!s->pull_on) return 0;
+    if (sync_and_check(s) != MDX_OK) return -1;
+    // records [popped, count) are complete after the synchronisation above
+    const long long count = s->pull_log_count;
+    long long start = s->pull_log_popped;
+    if (count - start > s->pull_log_cap) start = count - s->pull_log_cap;
+    const long long n = std::min(count - start, max_records);
+    for (long long k = 0; k < n; k++) memcpy(out + 4 * k, s->pull_log + 4 * ((start + k) % s->pull_log_cap), sizeof(double) * 4);
+    s->pull_log_popped = start + n;
+    return n;
+}

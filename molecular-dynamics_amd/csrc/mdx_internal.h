@@ -1,0 +1,184 @@
+// Internal state of one mdx system: one HIP device, one stream, all arrays resident in HBM.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hipfft/hipfft.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "mdx_math.h"
+#include "../../include/mdx.h"
+
+#define MDX_MAX_TC 8
+#define MDX_MAX_SHIFTS 48
+#define MDX_NB_CHUNK 32          // j-clusters per nonbonded work unit
+#define MDX_MAX_COL 2048         // atoms per grid column handled by the in-LDS sort
+#define MDX_LINCS_MAXK 16        // constraints per coupled component
+
+// Device-resident scalars: written by kernels, read by kernels, copied to the host on demand.
+struct DevState {
+    DevBox box;                   // float box used by every kernel
+    double boxd[9];               // master copy (double) updated by pressure coupling
+    // pair-search counters
+    int nsc;                      // super-clusters (64 atoms)
+    int ncj;                      // j-cluster entries
+    int nwork;                    // nonbonded work units
+    int nexcl;                    // exclusion-mask slots in use (slot 0 = all ones)
+    int overflow;                 // bit flags: 1 cj list, 2 work list, 4 mask list, 8 column too tall
+    int pad0[3];
+    // per-step accumulators
+    double ener[MDX_E_N];
+    double vir[9];                // -1/2 sum r (x) F of all force terms + constraints
+    double ekinh_old[MDX_MAX_TC]; // half-step kinetic energy per T-group before the update
+    double ekinh[MDX_MAX_TC];     // ... after the update
+    double ekin_tensor[9];        // average of the two half-step tensors (energy steps)
+    double lambda[MDX_MAX_TC];    // V-rescale scaling factor for the coming step
+    double therm_integral[MDX_MAX_TC];
+    double pres[9];               // pressure tensor (bar) of the last virial step
+    double mu[9];                 // box/coordinate scaling matrix of the last coupling step
+    double pr_boxv[9];            // Parrinello-Rahman box velocity
+    double pr_M[9];               // Parrinello-Rahman velocity coupling matrix
+    double baro_integral;
+    double com_v[4];              // COM momentum accumulators (px,py,pz,mass)
+    // pull
+    double pull_com[2][4];        // mass-weighted sums (x,y,z,m) per group
+    double pull_value, pull_force, pull_ref, pull_work;
+    double pull_init;             // reference value at t=0 (set by pull start)
+    int pull_have_init;
+    int pad1;
+    long long step;
+};
+
+struct NbEntry { int cj; unsigned int mask; };        // mask: bits 0-7 i-cluster mask, bits 8.. exclusion slot
+struct NbWork { int sci; int shift; int cj_start; int cj_end; };
+
+struct HostAtoms { std::vector<float> q, invm; };
+
+struct mdx_system {
+    int device = 0;
+    HostAtoms host_atoms;
+    std::vector<long long> frame_steps;   // steps of the energy frames not yet popped
+    long long pull_log_popped = 0;
+    bool pull_reset_pending = false;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int n = 0;                    // atoms
+    int npad = 0;                 // capacity of sorted arrays (multiple of 64)
+    // ---- state (original atom order)
+    float4 *x = nullptr;          // xyz + charge
+    float4 *xp = nullptr;         // scratch positions (unconstrained update)
+    float4 *v = nullptr;          // xyz + inverse mass
+    float *f = nullptr;           // 3N forces from bonded/PME/restraint kernels (original order)
+    float2 *lj = nullptr;         // (sigma/2, 2 sqrt(eps)) per atom
+    int *molid = nullptr;
+    int *tcgrp = nullptr;         // T-coupling group per atom
+    int *excl_start = nullptr, *excl_list = nullptr;
+    int n_excl_pairs = 0;
+    int2 *excl_pairs = nullptr;   // i<j list for the Ewald exclusion correction
+    double q2sum = 0.0;
+    // ---- sorted (cluster) layout
+    float4 *xq_s = nullptr;       // npad
+    float2 *lj_s = nullptr;
+    float *f_s = nullptr;         // 3*npad
+    int *perm = nullptr;          // sorted -> original (-1 filler)
+    int *perm_src = nullptr;      // sorted -> original atom whose position is used (always valid)
+    int *shift_s = nullptr;       // packed lattice shift applied when wrapping
+    int *molid_s = nullptr;
+    int *sorted_of = nullptr;     // original -> sorted
+    float4 *bb_lo = nullptr, *bb_hi = nullptr;     // per cluster
+    float4 *sbb_lo = nullptr, *sbb_hi = nullptr;   // per super-cluster
+    // grid
+    int ncx = 0, ncy = 0, ncol_cap = 0;
+    int *col_count = nullptr, *col_astart = nullptr, *col_scstart = nullptr, *col_atoms = nullptr;
+    int *atom_col = nullptr, *atom_slot = nullptr;
+    float4 *wrapped = nullptr;
+    // lists
+    NbEntry *cj = nullptr; int cj_cap = 0;
+    NbWork *work = nullptr; int work_cap = 0;
+    unsigned char *exclmask = nullptr; int excl_cap = 0;
+    int nshift = 0, central_shift = 0;
+    int3 *shift_ijk = nullptr;    // device
+    float4 *shiftvec = nullptr;   // device, refreshed each step from the box
+    std::vector<int3> h_shift_ijk;
+    // nonbonded parameters
+    float rc = 1.0f, rlist = 1.1f, beta = 3.12341f;
+    int nstlist = 10;
+    // PME
+    int K[3] = {0, 0, 0};
+    float *grid = nullptr; float2 *cgrid = nullptr;
+    float *bmod[3] = {nullptr, nullptr, nullptr};
+    hipfftHandle plan_r2c = 0, plan_c2r = 0;
+    bool have_pme = false;
+    // bonded
+    int nbonds = 0; int2 *bond_ij = nullptr; float2 *bond_p = nullptr;
+    int nangles = 0; int4 *angle_ijk = nullptr; float2 *angle_p = nullptr;
+    int ndih = 0; int4 *dih_ijkl = nullptr; float4 *dih_p = nullptr;
+    int npairs = 0; int2 *pair_ij = nullptr; float4 *pair_p = nullptr;
+    int nposres = 0; int *posres_idx = nullptr; float4 *posres_ref = nullptr; float4 *posres_k = nullptr;
+    int refcoord_scaling = 0;     // 0 no, 1 all, 2 com
+    // constraints
+    int nsettle = 0; int4 *settle_idx = nullptr; float settle_doh = 0, settle_dhh = 0;
+    int ncons = 0; int ncomp = 0;
+    int2 *cons_ij = nullptr; float *cons_len = nullptr; int *comp_start = nullptr;  // constraints sorted by component
+    int lincs_order = 4, lincs_iter = 1;
+    // integration / coupling
+    float dt = 0.002f;
+    int ntc = 0; double ref_t[MDX_MAX_TC] = {0}, tau_t[MDX_MAX_TC] = {0}, ndf[MDX_MAX_TC] = {0};
+    int nsttcouple = 10; uint64_t seed = 1;
+    double *d_tc = nullptr;       // device: ref_t, tau_t, ndf (3 x MDX_MAX_TC)
+    double ndf_total = 0;
+    int pcoupl = 0;               // 0 no, 1 C-rescale, 2 Parrinello-Rahman
+    double tau_p = 1.0, ref_p = 1.0, compress = 4.5e-5; int nstpcouple = 10;
+    int nstcomm = 100;
+    int nstcalcenergy = 100;
+    double dispcorr_c6avg = 0.0; int dispcorr = 0;   // 0 no, 1 Ener, 2 EnerPres
+    // pull
+    int pull_on = 0; int pull_n[2] = {0, 0}; int *pull_idx[2] = {nullptr, nullptr};
+    int pull_pbcatom[2] = {0, 0};
+    int pull_type = 0;            // 0 constant-force, 1 umbrella
+    double pull_k = 0, pull_rate = 0, pull_init_user = 0; int pull_start = 0;
+    int pull_dim[3] = {1, 1, 1};
+    int pull_nstout = 50;
+    double *pull_log = nullptr;   // pinned host ring: (time, value, force, work) records
+    int pull_log_cap = 0;
+    long long pull_log_count = 0;
+    // scalars
+    DevState *d = nullptr;        // device
+    DevState *h = nullptr;        // pinned host mirror
+    long long step = 0;           // host-side step counter (steps enqueued)
+    long long steps_since_search = 1 << 30;
+    bool first_step = true;
+    bool forces_current = false;
+    // energy history ring (pinned)
+    double *ener_log = nullptr; int ener_log_cap = 0; long long ener_log_count = 0;
+    // timing of the dominant kernel (HIP events on this stream)
+    bool time_nb = false; std::vector<hipEvent_t> ev_pool; std::vector<std::pair<int, int>> ev_nb;
+    double nb_ms_total = 0; long long nb_launches = 0;
+};
+
+#define MDX_CHECK(sys, call)                                                                         \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            (sys)->err = std::string(#call) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" +     \
+                         std::to_string(__LINE__) + ")";                                             \
+            return MDX_ERR_HIP;                                                                      \
+        }                                                                                            \
+    } while (0)
+
+// kernels' host launchers (each returns MDX_OK or an error code)
+int mdx_search(mdx_system *s);
+int mdx_launch_prepare(mdx_system *s);
+int mdx_launch_nonbonded(mdx_system *s, bool energy);
+int mdx_launch_pme(mdx_system *s, bool energy);
+int mdx_launch_bonded(mdx_system *s, bool energy, unsigned flags);
+int mdx_launch_pull(mdx_system *s, bool log_now, bool energy);
+int mdx_launch_update(mdx_system *s, bool do_tc, bool do_pr, bool virial);
+int mdx_launch_ke(mdx_system *s, bool old_slot, bool tensor);
+int mdx_launch_clear(mdx_system *s, bool energies, bool ekin_new, bool ekin_old);
+int mdx_launch_tcouple(mdx_system *s);
+int mdx_launch_pcouple(mdx_system *s);
+int mdx_launch_comm(mdx_system *s);
+int mdx_launch_finish_energy(mdx_system *s);
+int mdx_launch_merge_forces(mdx_system *s, float *out3n);
+int mdx_pme_init(mdx_system *s);
+void mdx_pme_free(mdx_system *s);

@@ -1,0 +1,183 @@
+// Fused LJ + Ewald real-space nonbonded kernel on the cluster-pair list (FP32 VALU).
+//
+// Replaces the short-range kernel that `coulombtype = PME`, `rcoulomb`, `rvdw`
+// (/root/reference/mdp/production.mdp:24-27; pull_short.mdp:19-21) switch on in gmx mdrun.
+//
+// One wave = one work unit = (i-super-cluster of 8x8 atoms, lattice shift, <= 32 j-clusters).
+// Lane (ti = lane & 7, tj = lane >> 3) holds i-atom ti of all 8 i-clusters in registers and, per
+// j-cluster, j-atom tj: one wave instruction evaluates an 8x8 atom tile. i-forces accumulate in
+// registers for the whole unit; the j-force is reduced over the 8 lanes sharing tj with DPP-style
+// butterflies and added to the sorted force buffer with one 24-lane float atomic per j-cluster.
+// Pair arithmetic: F/r = [4 eps (12 s6^2 - 6 s6) + qq (erfc(br) + 2/sqrt(pi) br exp(-b^2 r^2)) / r] / r^2
+// with Lorentz-Berthelot sigma/eps from per-atom (sigma/2, 2 sqrt(eps)) so no type table gather.
+#include "mdx_internal.h"
+
+struct NbArgs {
+    const DevState *d;
+    const NbWork *work;
+    const NbEntry *cj;
+    const unsigned char *exclmask;
+    const float4 *xq_s;
+    const float2 *lj_s;
+    const float4 *shiftvec;
+    float *f_s;
+    DevState *dw;
+    float rc2, beta, c_rf_shift; // c_rf_shift = erfc(beta rc)/rc
+    float inv_rc6;               // 1/rc^6
+};
+
+// Cross-lane adds inside groups of 8 consecutive lanes as DPP moves (no LDS crossbar traffic).
+__device__ __forceinline__ float dpp_quad_x1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)); }
+__device__ __forceinline__ float dpp_quad_x2(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)); }
+__device__ __forceinline__ float dpp_half_mirror(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)); }
+__device__ __forceinline__ float dpp_row_ror8(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, true)); }
+__device__ __forceinline__ float sum8(float v)
+{
+    v += dpp_quad_x1(v);
+    v += dpp_quad_x2(v);
+    v += dpp_half_mirror(v);
+    return v;
+}
+
+template <bool ENERGY>
+__global__ __launch_bounds__(256) void k_nonbonded(NbArgs A)
+{
+    const int lane = threadIdx.x & 63;
+    const int ti = lane & 7, tj = lane >> 3;
+    const int nwork = A.d->nwork;
+    const int nwaves = gridDim.x * 4;
+    float elj = 0.0f, ecoul = 0.0f;
+    float vxx = 0.0f, vxy = 0.0f, vxz = 0.0f, vyy = 0.0f, vyz = 0.0f, vzz = 0.0f;
+    const float rc2 = A.rc2, beta = A.beta;
+    const float nb2l2e = -beta * beta * 1.4426950408889634f; // exp(-b^2 r^2) = exp2(nb2l2e * r2)
+  for (int unit = blockIdx.x * 4 + (threadIdx.x >> 6); unit < nwork; unit += nwaves) {
+    const NbWork w = A.work[unit];
+    const float4 S = A.shiftvec[w.shift];
+    float xi[8], yi[8], zi[8], qi[8], hsi[8], sei[8];
+    float fix[8], fiy[8], fiz[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const int ia = (w.sci * 8 + c) * 8 + ti;
+        const float4 p = A.xq_s[ia];
+        const float2 l = A.lj_s[ia];
+        xi[c] = p.x - S.x; yi[c] = p.y - S.y; zi[c] = p.z - S.z;
+        qi[c] = p.w * MDX_ONE_4PI_EPS0;
+        hsi[c] = l.x; sei[c] = l.y;
+        fix[c] = 0.0f; fiy[c] = 0.0f; fiz[c] = 0.0f;
+    }
+
+    for (int e = w.cj_start; e < w.cj_end; e++) {
+        const NbEntry ent = A.cj[e];
+        const int cj = __builtin_amdgcn_readfirstlane(ent.cj);
+        const unsigned mk = __builtin_amdgcn_readfirstlane(ent.mask);
+        const unsigned imask = mk & 0xFFu;
+        const unsigned slot = mk >> 8;
+        const int ja = cj * 8 + tj;
+        const float4 pj = A.xq_s[ja];
+        const float2 lj = A.lj_s[ja];
+        unsigned ex = 0xFFu;
+        if (slot) ex = A.exclmask[(size_t)slot * 64 + lane];
+        float fjx = 0.0f, fjy = 0.0f, fjz = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            if (imask & (1u << c)) {
+                const float dx = xi[c] - pj.x, dy = yi[c] - pj.y, dz = zi[c] - pj.z;
+                float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                const bool within = (r2 < rc2) && ((ex >> c) & 1u);
+                r2 = fmaxf(r2, 1.0e-12f);
+                const float rinv = __frsqrt_rn(r2);
+                const float rinv2 = rinv * rinv;
+                // Lennard-Jones
+                const float sg = hsi[c] + lj.x;
+                const float e4 = sei[c] * lj.y;
+                const float s2 = sg * sg * rinv2;
+                const float s6 = s2 * s2 * s2;
+                const float t6 = e4 * s6;
+                float fs = t6 * fmaf(12.0f, s6, -6.0f);
+                // Ewald real space
+                const float qq = qi[c] * pj.w;
+                const float br = beta * r2 * rinv;
+                const float ex2 = __builtin_amdgcn_exp2f(nb2l2e * r2);
+                const float erfc_br = ex2 * mdx_erfcx_poly(br);
+                const float cf = qq * rinv;
+                fs = fmaf(cf, fmaf(MDX_2_SQRTPI * br, ex2, erfc_br), fs);
+                fs *= rinv2;
+                fs = within ? fs : 0.0f;
+                const float fx = fs * dx, fy = fs * dy, fz = fs * dz;
+                fix[c] += fx; fiy[c] += fy; fiz[c] += fz;
+                fjx -= fx; fjy -= fy; fjz -= fz;
+                if (ENERGY) {
+                    if (within) {
+                        const float c2 = sg * sg * (1.0f / rc2);
+                        const float c6 = c2 * c2 * c2;
+                        elj += e4 * (fmaf(s6, s6, -s6) - fmaf(c6, c6, -c6));
+                        ecoul += qq * (erfc_br * rinv - A.c_rf_shift);
+                    }
+                    vxx = fmaf(dx, fx, vxx); vxy = fmaf(dx, fy, vxy); vxz = fmaf(dx, fz, vxz);
+                    vyy = fmaf(dy, fy, vyy); vyz = fmaf(dy, fz, vyz); vzz = fmaf(dz, fz, vzz);
+                }
+            }
+        }
+        // reduce the j force over the 8 lanes with equal tj (consecutive lanes)
+        fjx = sum8(fjx); fjy = sum8(fjy); fjz = sum8(fjz);
+        if (ti < 3) {
+            const float val = (ti == 0) ? fjx : ((ti == 1) ? fjy : fjz);
+            atomicAdd(&A.f_s[3 * ja + ti], val);
+        }
+    }
+    // reduce i forces over tj (lanes 8 apart) and add
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        float ax = fix[c], ay = fiy[c], az = fiz[c];
+        ax += dpp_row_ror8(ax); ay += dpp_row_ror8(ay); az += dpp_row_ror8(az);
+        ax += __shfl_xor(ax, 16, 64); ay += __shfl_xor(ay, 16, 64); az += __shfl_xor(az, 16, 64);
+        ax += __shfl_xor(ax, 32, 64); ay += __shfl_xor(ay, 32, 64); az += __shfl_xor(az, 32, 64);
+        if (tj < 3) {
+            const float val = (tj == 0) ? ax : ((tj == 1) ? ay : az);
+            atomicAdd(&A.f_s[3 * ((w.sci * 8 + c) * 8 + ti) + tj], val);
+        }
+    }
+  }
+    if (ENERGY) {
+        elj = wave_sum(elj); ecoul = wave_sum(ecoul);
+        vxx = wave_sum(vxx); vxy = wave_sum(vxy); vxz = wave_sum(vxz);
+        vyy = wave_sum(vyy); vyz = wave_sum(vyz); vzz = wave_sum(vzz);
+        if (lane == 0) {
+            atomicAdd(&A.dw->ener[MDX_E_LJ], (double)elj);
+            atomicAdd(&A.dw->ener[MDX_E_COUL_SR], (double)ecoul);
+            double *v = A.dw->vir;
+            atomicAdd(&v[0], -0.5 * vxx); atomicAdd(&v[1], -0.5 * vxy); atomicAdd(&v[2], -0.5 * vxz);
+            atomicAdd(&v[3], -0.5 * vxy); atomicAdd(&v[4], -0.5 * vyy); atomicAdd(&v[5], -0.5 * vyz);
+            atomicAdd(&v[6], -0.5 * vxz); atomicAdd(&v[7], -0.5 * vyz); atomicAdd(&v[8], -0.5 * vzz);
+        }
+    }
+}
+
+int mdx_launch_nonbonded(mdx_system *s, bool energy)
+{
+    NbArgs A;
+    A.d = s->d; A.dw = s->d; A.work = s->work; A.cj = s->cj; A.exclmask = s->exclmask; A.xq_s = s->xq_s; A.lj_s = s->lj_s;
+    A.shiftvec = s->shiftvec; A.f_s = s->f_s;
+    A.rc2 = s->rc * s->rc; A.beta = s->beta;
+    A.c_rf_shift = (float)(erfc((double)s->beta * s->rc) / s->rc);
+    A.inv_rc6 = 1.0f / (A.rc2 * A.rc2 * A.rc2);
+    // grid-stride over work units: the unit count lives in device memory, so the grid is fixed
+    // (4 blocks of 4 waves per CU) and every wave exits once the list is exhausted
+    const int nblk = 1024;
+    int e0 = -1, e1 = -1;
+    if (s->time_nb) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { s->err = "hipEventCreate failed"; return MDX_ERR_HIP; }
+        s->ev_pool.push_back(a); s->ev_pool.push_back(b);
+        e0 = (int)s->ev_pool.size() - 2; e1 = e0 + 1;
+        MDX_CHECK(s, hipEventRecord(s->ev_pool[e0], s->stream));
+    }
+    if (energy) hipLaunchKernelGGL(k_nonbonded<true>, dim3(nblk), dim3(256), 0, s->stream, A);
+    else hipLaunchKernelGGL(k_nonbonded<false>, dim3(nblk), dim3(256), 0, s->stream, A);
+    MDX_CHECK(s, hipGetLastError());
+    if (s->time_nb) {
+        MDX_CHECK(s, hipEventRecord(s->ev_pool[e1], s->stream));
+        s->ev_nb.push_back(std::make_pair(e0, e1));
+    }
+    return MDX_OK;
+}

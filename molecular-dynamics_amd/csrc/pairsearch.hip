@@ -1,0 +1,460 @@
+// Verlet cluster-pair list builder (Pall & Hess 2013 scheme, laid out for wave64).
+//
+// Replaces the pair search that `cutoff-scheme = Verlet`, `nstlist`, `rlist`
+// (/root/reference/mdp/production.mdp:21-23, pull_short.mdp:16-18) switch on inside gmx mdrun.
+//
+// Layout: atoms are wrapped into the rectangular brick [0,ax) x [0,by) x [0,cz) that is a unit
+// cell of every lower-triangular (GROMACS-convention) box, binned into xy columns, sorted along z
+// inside a column (in LDS), cut into super-clusters of 64 atoms, and each super-cluster is split
+// by a y-sort of its two z-halves and an x-sort of its four quarters into 8 clusters of 8 atoms.
+// One wave builds the list of one i-super-cluster: for every lattice shift it tests bounding
+// boxes, then all 8x8 atom pairs of each surviving cluster pair with one lane per pair, and emits
+// (j-cluster, 8-bit i-cluster mask, exclusion-mask slot) entries plus work units of at most
+// MDX_NB_CHUNK entries for the nonbonded kernel.
+#include "mdx_internal.h"
+
+#define BIG_KEY 3.0e38f
+
+__device__ __forceinline__ int pack_shift(int a, int b, int c) { return (a + 512) | ((b + 512) << 10) | ((c + 512) << 20); }
+__device__ __forceinline__ void unpack_shift(int p, int &a, int &b, int &c)
+{
+    a = (p & 1023) - 512; b = ((p >> 10) & 1023) - 512; c = ((p >> 20) & 1023) - 512;
+}
+
+__global__ void k_bin(int n, const float4 *__restrict__ x, const DevState *__restrict__ d, int ncx, int ncy,
+                      int *__restrict__ col_count, float4 *__restrict__ wrapped, int *__restrict__ atom_col,
+                      int *__restrict__ atom_slot)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *h = d->box.h;
+    float4 p = x[i];
+    int nc = (int)floorf(p.z / h[8]);
+    p.x -= nc * h[6]; p.y -= nc * h[7]; p.z -= nc * h[8];
+    int nb = (int)floorf(p.y / h[4]);
+    p.x -= nb * h[3]; p.y -= nb * h[4];
+    int na = (int)floorf(p.x / h[0]);
+    p.x -= na * h[0];
+    int cx = min(ncx - 1, max(0, (int)(p.x * ncx / h[0])));
+    int cy = min(ncy - 1, max(0, (int)(p.y * ncy / h[4])));
+    const int col = cy * ncx + cx;
+    const int slot = atomicAdd(&col_count[col], 1);
+    p.w = __int_as_float(pack_shift(-na, -nb, -nc));
+    wrapped[i] = p;
+    atom_col[i] = col;
+    atom_slot[i] = slot;
+}
+
+// One block: exclusive prefix sums of column atom counts and of column super-cluster counts.
+__global__ void k_colscan(int ncol, const int *__restrict__ col_count, int *__restrict__ col_astart,
+                          int *__restrict__ col_scstart, DevState *__restrict__ d, int nsc_cap)
+{
+    __shared__ int sa[1024], ss[1024];
+    const int t = threadIdx.x;
+    const int per = (ncol + blockDim.x - 1) / blockDim.x;
+    const int b = t * per, e = min(ncol, b + per);
+    int a = 0, s = 0;
+    for (int c = b; c < e; c++) { a += col_count[c]; s += (col_count[c] + 63) >> 6; }
+    sa[t] = a; ss[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        int ra = 0, rs = 0;
+        for (int k = 0; k < (int)blockDim.x; k++) { int ta = sa[k], ts = ss[k]; sa[k] = ra; ss[k] = rs; ra += ta; rs += ts; }
+        col_astart[ncol] = ra; col_scstart[ncol] = rs;
+        d->nsc = rs; d->ncj = 0; d->nwork = 0; d->nexcl = 1;
+        if (rs > nsc_cap) d->overflow |= 16;
+    }
+    __syncthreads();
+    a = sa[t]; s = ss[t];
+    for (int c = b; c < e; c++) {
+        col_astart[c] = a; col_scstart[c] = s;
+        const int cnt = col_count[c];
+        if (cnt > MDX_MAX_COL) d->overflow |= 8;
+        a += cnt; s += (cnt + 63) >> 6;
+    }
+}
+
+__global__ void k_fill(int n, const int *__restrict__ atom_col, const int *__restrict__ atom_slot,
+                       const int *__restrict__ col_astart, int *__restrict__ col_atoms)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    col_atoms[col_astart[atom_col[i]] + atom_slot[i]] = i;
+}
+
+// Bitonic sort of aligned blocks of B (power of two) elements by key k[], ascending; carries
+// three companion arrays. All threads of the block must call.
+__device__ void bitonic_blocks(float *k, float *c1, float *c2, int *id, int P, int B)
+{
+    for (int kk = 2; kk <= B; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < P; t += blockDim.x) {
+                const int u = t ^ j;
+                if (u > t) {
+                    const bool up = ((t & kk & (B - 1)) == 0);
+                    const float a = k[t], b = k[u];
+                    // ties broken by atom index for a deterministic order
+                    const bool gt = (a > b) || (a == b && id[t] > id[u]);
+                    if (gt == up) {
+                        k[t] = b; k[u] = a;
+                        float w = c1[t]; c1[t] = c1[u]; c1[u] = w;
+                        w = c2[t]; c2[t] = c2[u]; c2[u] = w;
+                        int q = id[t]; id[t] = id[u]; id[u] = q;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sortcol(const int *__restrict__ col_count, const int *__restrict__ col_astart,
+                                                 const int *__restrict__ col_scstart, const int *__restrict__ col_atoms,
+                                                 const float4 *__restrict__ wrapped, const float4 *__restrict__ x,
+                                                 const float2 *__restrict__ lj, const int *__restrict__ molid,
+                                                 float4 *__restrict__ xq_s, float2 *__restrict__ lj_s, int *__restrict__ perm,
+                                                 int *__restrict__ perm_src, int *__restrict__ shift_s, int *__restrict__ molid_s,
+                                                 int *__restrict__ sorted_of, float4 *__restrict__ bb_lo, float4 *__restrict__ bb_hi,
+                                                 float4 *__restrict__ sbb_lo, float4 *__restrict__ sbb_hi, int nsc_cap)
+{
+    __shared__ float kz[MDX_MAX_COL], ky[MDX_MAX_COL], kx[MDX_MAX_COL];
+    __shared__ int id[MDX_MAX_COL];
+    const int col = blockIdx.x;
+    const int n = min(col_count[col], MDX_MAX_COL);
+    if (n == 0) return;
+    const int base = col_astart[col];
+    const int nscol = (n + 63) >> 6;
+    const int sc0 = col_scstart[col];
+    if (sc0 + nscol > nsc_cap) return;
+    int P = 64;
+    while (P < nscol * 64) P <<= 1;
+    for (int t = threadIdx.x; t < P; t += blockDim.x) {
+        if (t < n) {
+            const int a = col_atoms[base + t];
+            const float4 w = wrapped[a];
+            kz[t] = w.z; ky[t] = w.y; kx[t] = w.x; id[t] = a;
+        } else {
+            kz[t] = BIG_KEY; ky[t] = BIG_KEY; kx[t] = BIG_KEY; id[t] = 0x7fffffff;
+        }
+    }
+    __syncthreads();
+    bitonic_blocks(kz, ky, kx, id, P, P);
+    bitonic_blocks(ky, kz, kx, id, nscol * 64 <= P ? P : P, 32);   // each 32-half of a super-cluster by y
+    bitonic_blocks(kx, ky, kz, id, P, 16);                          // each 16-quarter by x
+    // emit
+    const int ntot = nscol * 64;
+    for (int t = threadIdx.x; t < ntot; t += blockDim.x) {
+        const int g = sc0 * 64 + t;
+        int a = id[t];
+        int src = t;
+        const bool filler = (a == 0x7fffffff);
+        if (filler) {
+            src = t & ~7;
+            if (id[src] == 0x7fffffff) src = t & ~63;
+        }
+        const int as = id[src];
+        const float4 w = wrapped[as];
+        const float q = filler ? 0.0f : x[as].w;
+        xq_s[g] = make_float4(w.x, w.y, w.z, q);
+        lj_s[g] = filler ? make_float2(0.0f, 0.0f) : lj[as];
+        perm[g] = filler ? -1 : a;
+        perm_src[g] = as;
+        shift_s[g] = __float_as_int(w.w);
+        molid_s[g] = filler ? -1 : molid[as];
+        if (!filler) sorted_of[a] = g;
+    }
+    __syncthreads();
+    // cluster bounding boxes (fillers sit on a real atom of the same super-cluster, so a cluster
+    // made only of fillers degenerates to a point inside the super-cluster)
+    for (int c = threadIdx.x; c < nscol * 8; c += blockDim.x) {
+        float lo[3] = { BIG_KEY, BIG_KEY, BIG_KEY }, hi[3] = { -BIG_KEY, -BIG_KEY, -BIG_KEY };
+        for (int k = 0; k < 8; k++) {
+            int t = c * 8 + k;
+            if (id[t] == 0x7fffffff) { t = t & ~7; if (id[t] == 0x7fffffff) t = t & ~63; }
+            lo[0] = fminf(lo[0], kx[t]); hi[0] = fmaxf(hi[0], kx[t]);
+            lo[1] = fminf(lo[1], ky[t]); hi[1] = fmaxf(hi[1], ky[t]);
+            lo[2] = fminf(lo[2], kz[t]); hi[2] = fmaxf(hi[2], kz[t]);
+        }
+        bb_lo[sc0 * 8 + c] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+        bb_hi[sc0 * 8 + c] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    }
+    for (int sc = threadIdx.x; sc < nscol; sc += blockDim.x) {
+        float lo[3] = { BIG_KEY, BIG_KEY, BIG_KEY }, hi[3] = { -BIG_KEY, -BIG_KEY, -BIG_KEY };
+        for (int k = 0; k < 64; k++) {
+            const int t = sc * 64 + k;
+            if (id[t] == 0x7fffffff) continue;
+            lo[0] = fminf(lo[0], kx[t]); hi[0] = fmaxf(hi[0], kx[t]);
+            lo[1] = fminf(lo[1], ky[t]); hi[1] = fmaxf(hi[1], ky[t]);
+            lo[2] = fminf(lo[2], kz[t]); hi[2] = fmaxf(hi[2], kz[t]);
+        }
+        sbb_lo[sc0 + sc] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+        sbb_hi[sc0 + sc] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    }
+}
+
+__device__ __forceinline__ float bb_dist2(float3 alo, float3 ahi, float4 blo, float4 bhi)
+{
+    const float dx = fmaxf(0.0f, fmaxf(alo.x - bhi.x, blo.x - ahi.x));
+    const float dy = fmaxf(0.0f, fmaxf(alo.y - bhi.y, blo.y - ahi.y));
+    const float dz = fmaxf(0.0f, fmaxf(alo.z - bhi.z, blo.z - ahi.z));
+    return dx * dx + dy * dy + dz * dz;
+}
+
+struct ListArgs {
+    const DevState *dro;
+    DevState *d;
+    int ncx, ncy;
+    const int *col_scstart;
+    const float4 *xq_s;
+    const int *perm;
+    const int *molid_s;
+    const float4 *bb_lo, *bb_hi, *sbb_lo, *sbb_hi;
+    const float4 *shiftvec;
+    int nshift, central;
+    const int *excl_start, *excl_list;
+    NbEntry *cj; int cj_cap;
+    NbWork *work; int work_cap;
+    unsigned char *exclmask; int excl_cap;
+    float rlist;
+};
+
+#define EBUF 256
+
+__global__ __launch_bounds__(256) void k_build_list(ListArgs A)
+{
+    __shared__ float4 xi_sh[4][64];
+    __shared__ int mol_sh[4][64];
+    __shared__ int orig_sh[4][64];
+    __shared__ NbEntry ebuf[4][EBUF];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int sci = blockIdx.x * 4 + wv;
+    const int nsc = A.dro->nsc;
+    if (sci >= nsc) return;
+    const float rl2 = A.rlist * A.rlist;
+    const float *h = A.dro->box.h;
+    const float wx = h[0] / A.ncx, wy = h[4] / A.ncy, cz = h[8];
+    xi_sh[wv][lane] = A.xq_s[sci * 64 + lane];
+    mol_sh[wv][lane] = A.molid_s[sci * 64 + lane];
+    orig_sh[wv][lane] = A.perm[sci * 64 + lane];
+    const float4 slo4 = A.sbb_lo[sci], shi4 = A.sbb_hi[sci];
+    const int ti = lane & 7, tj = lane >> 3;
+    const float4 ilo4 = A.bb_lo[sci * 8 + ti], ihi4 = A.bb_hi[sci * 8 + ti];
+    __builtin_amdgcn_wave_barrier();
+    NbEntry *eb = ebuf[wv];
+
+    for (int s = 0; s < A.nshift; s++) {
+        const float4 S = A.shiftvec[s];
+        const bool central = (s == A.central);
+        const float3 slo = make_float3(slo4.x - S.x, slo4.y - S.y, slo4.z - S.z);
+        const float3 shi = make_float3(shi4.x - S.x, shi4.y - S.y, shi4.z - S.z);
+        if (shi.z + A.rlist < 0.0f || slo.z - A.rlist > cz) continue;
+        const int cx0 = max(0, (int)floorf((slo.x - A.rlist) / wx)), cx1 = min(A.ncx - 1, (int)floorf((shi.x + A.rlist) / wx));
+        const int cy0 = max(0, (int)floorf((slo.y - A.rlist) / wy)), cy1 = min(A.ncy - 1, (int)floorf((shi.y + A.rlist) / wy));
+        if (cx0 > cx1 || cy0 > cy1) continue;
+        const float3 ilo = make_float3(ilo4.x - S.x, ilo4.y - S.y, ilo4.z - S.z);
+        const float3 ihi = make_float3(ihi4.x - S.x, ihi4.y - S.y, ihi4.z - S.z);
+        int nent = 0;
+        for (int cy = cy0; cy <= cy1; cy++)
+            for (int cx = cx0; cx <= cx1; cx++) {
+                const int col = cy * A.ncx + cx;
+                const int scb = A.col_scstart[col], sce = A.col_scstart[col + 1];
+                for (int base = scb; base < sce; base += 64) {
+                    const int scj_l = base + lane;
+                    bool ok = scj_l < sce;
+                    if (central) ok = ok && (scj_l >= sci);
+                    if (ok) ok = bb_dist2(slo, shi, A.sbb_lo[scj_l], A.sbb_hi[scj_l]) < rl2;
+                    unsigned long long m = __ballot(ok);
+                    while (m) {
+                        const int b = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const int scj = base + b;
+                        // cluster level: lane = (i-cluster ti, j-cluster tj)
+                        bool okc = bb_dist2(ilo, ihi, A.bb_lo[scj * 8 + tj], A.bb_hi[scj * 8 + tj]) < rl2;
+                        if (central && scj == sci) okc = okc && (tj >= ti);
+                        const unsigned long long cm = __ballot(okc);
+                        for (int cjl = 0; cjl < 8; cjl++) {
+                            const unsigned im = (unsigned)((cm >> (8 * cjl)) & 0xFFull);
+                            if (!im) continue;
+                            const int cjg = scj * 8 + cjl;
+                            // atom level: lane = (i-atom ti, j-atom tj)
+                            const float4 xj = A.xq_s[cjg * 8 + tj];
+                            const int molj = A.molid_s[cjg * 8 + tj];
+                            const int origj = A.perm[cjg * 8 + tj];
+                            unsigned newim = 0, exb = 0xFF;
+                            for (int ci = 0; ci < 8; ci++) {
+                                if (!(im & (1u << ci))) continue;
+                                const float4 xi = xi_sh[wv][ci * 8 + ti];
+                                const float dx = xi.x - S.x - xj.x, dy = xi.y - S.y - xj.y, dz = xi.z - S.z - xj.z;
+                                const bool in = (dx * dx + dy * dy + dz * dz) < rl2;
+                                bool ex = false;
+                                if (central && cjg == sci * 8 + ci) {
+                                    ex = (tj <= ti);
+                                } else if (molj >= 0 && mol_sh[wv][ci * 8 + ti] == molj) {
+                                    const int oi = orig_sh[wv][ci * 8 + ti];
+                                    const int e0 = A.excl_start[oi], e1 = A.excl_start[oi + 1];
+                                    for (int k = e0; k < e1; k++)
+                                        if (A.excl_list[k] == origj) { ex = true; break; }
+                                }
+                                if (ex) exb &= ~(1u << ci);
+                                if (__any(in)) newim |= (1u << ci);
+                            }
+                            if (!newim) continue;
+                            const bool need = __any((exb & newim) != newim);
+                            int slot = 0;
+                            if (need) {
+                                if (lane == 0) slot = atomicAdd(&A.d->nexcl, 1);
+                                slot = __shfl(slot, 0, 64);
+                                if (slot < A.excl_cap) A.exclmask[(size_t)slot * 64 + lane] = (unsigned char)exb;
+                                else { slot = 0; if (lane == 0) atomicOr(&A.d->overflow, 4); }
+                            }
+                            if (lane == 0) { eb[nent].cj = cjg; eb[nent].mask = newim | ((unsigned)slot << 8); }
+                            nent++;
+                            if (nent == EBUF) {
+                                // flush a full buffer
+                                int start = 0, w0 = 0;
+                                const int nw = (nent + MDX_NB_CHUNK - 1) / MDX_NB_CHUNK;
+                                if (lane == 0) { start = atomicAdd(&A.d->ncj, nent); w0 = atomicAdd(&A.d->nwork, nw); }
+                                start = __shfl(start, 0, 64); w0 = __shfl(w0, 0, 64);
+                                __builtin_amdgcn_wave_barrier();
+                                if (start + nent <= A.cj_cap && w0 + nw <= A.work_cap) {
+                                    for (int k = lane; k < nent; k += 64) A.cj[start + k] = eb[k];
+                                    for (int k = lane; k < nw; k += 64) {
+                                        NbWork w; w.sci = sci; w.shift = s; w.cj_start = start + k * MDX_NB_CHUNK;
+                                        w.cj_end = min(start + nent, w.cj_start + MDX_NB_CHUNK);
+                                        A.work[w0 + k] = w;
+                                    }
+                                } else if (lane == 0) atomicOr(&A.d->overflow, (start + nent > A.cj_cap) ? 1 : 2);
+                                __builtin_amdgcn_wave_barrier();
+                                nent = 0;
+                            }
+                        }
+                    }
+                }
+            }
+        if (nent) {
+            int start = 0, w0 = 0;
+            const int nw = (nent + MDX_NB_CHUNK - 1) / MDX_NB_CHUNK;
+            if (lane == 0) { start = atomicAdd(&A.d->ncj, nent); w0 = atomicAdd(&A.d->nwork, nw); }
+            start = __shfl(start, 0, 64); w0 = __shfl(w0, 0, 64);
+            __builtin_amdgcn_wave_barrier();
+            if (start + nent <= A.cj_cap && w0 + nw <= A.work_cap) {
+                for (int k = lane; k < nent; k += 64) A.cj[start + k] = eb[k];
+                for (int k = lane; k < nw; k += 64) {
+                    NbWork w; w.sci = sci; w.shift = s; w.cj_start = start + k * MDX_NB_CHUNK;
+                    w.cj_end = min(start + nent, w.cj_start + MDX_NB_CHUNK);
+                    A.work[w0 + k] = w;
+                }
+            } else if (lane == 0) atomicOr(&A.d->overflow, (start + nent > A.cj_cap) ? 1 : 2);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// Per step: refresh the sorted coordinates from the state and clear the sorted force buffer.
+__global__ void k_prepare(int npad, const DevState *__restrict__ d, const float4 *__restrict__ x,
+                          const int *__restrict__ perm, const int *__restrict__ perm_src,
+                          const int *__restrict__ shift_s, float4 *__restrict__ xq_s, float *__restrict__ f_s,
+                          int nshift, const int3 *__restrict__ shift_ijk, float4 *__restrict__ shiftvec)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const float *h = d->box.h;
+    if (g < nshift) {
+        const int3 s = shift_ijk[g];
+        shiftvec[g] = make_float4(s.x * h[0] + s.y * h[3] + s.z * h[6], s.y * h[4] + s.z * h[7], s.z * h[8], 0.0f);
+    }
+    if (g >= d->nsc * 64 || g >= npad) return;
+    const int a = perm_src[g];
+    const float4 p = x[a];
+    int sa, sb, sc;
+    unpack_shift(shift_s[g], sa, sb, sc);
+    float4 o;
+    o.x = p.x + sa * h[0] + sb * h[3] + sc * h[6];
+    o.y = p.y + sb * h[4] + sc * h[7];
+    o.z = p.z + sc * h[8];
+    o.w = perm[g] >= 0 ? p.w : 0.0f;
+    xq_s[g] = o;
+    f_s[3 * g] = 0.0f; f_s[3 * g + 1] = 0.0f; f_s[3 * g + 2] = 0.0f;
+}
+
+__global__ void k_shiftvec(const DevState *__restrict__ d, int nshift, const int3 *__restrict__ shift_ijk,
+                           float4 *__restrict__ shiftvec)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const float *h = d->box.h;
+    if (g < nshift) {
+        const int3 s = shift_ijk[g];
+        shiftvec[g] = make_float4(s.x * h[0] + s.y * h[3] + s.z * h[6], s.y * h[4] + s.z * h[7], s.z * h[8], 0.0f);
+    }
+}
+
+int mdx_launch_prepare(mdx_system *s)
+{
+    const int nb = (s->npad + 255) / 256;
+    hipLaunchKernelGGL(k_prepare, dim3(nb), dim3(256), 0, s->stream, s->npad, s->d, s->x, s->perm, s->perm_src,
+                       s->shift_s, s->xq_s, s->f_s, s->nshift, s->shift_ijk, s->shiftvec);
+    MDX_CHECK(s, hipGetLastError());
+    return MDX_OK;
+}
+
+// Lattice shifts (i a + j b + k c) whose image of the brick can lie within rlist of the brick;
+// only one of each +/- pair is kept (the central image is listed with cj >= ci).
+static void build_shift_list(mdx_system *s, const double *box)
+{
+    s->h_shift_ijk.clear();
+    const double ax = box[0], bx = box[3], by = box[4], cx = box[6], cy = box[7], cz = box[8];
+    const double rl = s->rlist * 1.05 + 0.05;
+    for (int k = 0; k <= 1; k++)
+        for (int j = -2; j <= 2; j++)
+            for (int i = -3; i <= 3; i++) {
+                const bool half = (k > 0) || (k == 0 && j > 0) || (k == 0 && j == 0 && i >= 0);
+                if (!half) continue;
+                const double sx = i * ax + j * bx + k * cx, sy = j * by + k * cy, sz = k * cz;
+                // gap between brick and shifted brick per dimension
+                const double gx = fmax(0.0, fabs(sx) - ax), gy = fmax(0.0, fabs(sy) - by), gz = fmax(0.0, fabs(sz) - cz);
+                if (gx * gx + gy * gy + gz * gz >= rl * rl) continue;
+                if (i == 0 && j == 0 && k == 0) s->central_shift = (int)s->h_shift_ijk.size();
+                s->h_shift_ijk.push_back(make_int3(i, j, k));
+            }
+    s->nshift = (int)s->h_shift_ijk.size();
+}
+
+int mdx_search(mdx_system *s)
+{
+    // host copy of the box (may lag the device by a few coupling steps; only used for grid counts)
+    const double *box = s->h->boxd;
+    build_shift_list(s, box);
+    if (s->nshift > MDX_MAX_SHIFTS) { s->err = "too many lattice shifts (box too small for rlist)"; return MDX_ERR_UNSUPPORTED; }
+    MDX_CHECK(s, hipMemcpyAsync(s->shift_ijk, s->h_shift_ijk.data(), sizeof(int3) * s->nshift, hipMemcpyHostToDevice, s->stream));
+    // column grid: super-cluster cells roughly cubic
+    const double vol = box[0] * box[4] * box[8];
+    const double dens = s->n / vol;
+    double side = cbrt(64.0 / dens);
+    int ncx = (int)fmax(1.0, floor(box[0] / side)), ncy = (int)fmax(1.0, floor(box[4] / side));
+    // keep the expected column population within the in-LDS sort capacity
+    while ((double)s->n / (ncx * ncy) > 0.55 * MDX_MAX_COL) { ncx++; ncy++; }
+    while (ncx * ncy > s->ncol_cap) { if (ncx >= ncy) ncx--; else ncy--; }
+    s->ncx = ncx; s->ncy = ncy;
+    const int ncol = ncx * ncy;
+    MDX_CHECK(s, hipMemsetAsync(s->col_count, 0, sizeof(int) * (ncol + 1), s->stream));
+    const int nbk = (s->n + 255) / 256;
+    hipLaunchKernelGGL(k_bin, dim3(nbk), dim3(256), 0, s->stream, s->n, s->x, s->d, ncx, ncy, s->col_count, s->wrapped,
+                       s->atom_col, s->atom_slot);
+    hipLaunchKernelGGL(k_colscan, dim3(1), dim3(1024), 0, s->stream, ncol, s->col_count, s->col_astart, s->col_scstart,
+                       s->d, s->npad / 64);
+    hipLaunchKernelGGL(k_fill, dim3(nbk), dim3(256), 0, s->stream, s->n, s->atom_col, s->atom_slot, s->col_astart, s->col_atoms);
+    hipLaunchKernelGGL(k_sortcol, dim3(ncol), dim3(256), 0, s->stream, s->col_count, s->col_astart, s->col_scstart,
+                       s->col_atoms, s->wrapped, s->x, s->lj, s->molid, s->xq_s, s->lj_s, s->perm, s->perm_src, s->shift_s,
+                       s->molid_s, s->sorted_of, s->bb_lo, s->bb_hi, s->sbb_lo, s->sbb_hi, s->npad / 64);
+    hipLaunchKernelGGL(k_shiftvec, dim3(1), dim3(64), 0, s->stream, s->d, s->nshift, s->shift_ijk, s->shiftvec);
+    ListArgs A;
+    A.dro = s->d; A.d = s->d; A.ncx = ncx; A.ncy = ncy; A.col_scstart = s->col_scstart; A.xq_s = s->xq_s; A.perm = s->perm;
+    A.molid_s = s->molid_s; A.bb_lo = s->bb_lo; A.bb_hi = s->bb_hi; A.sbb_lo = s->sbb_lo; A.sbb_hi = s->sbb_hi;
+    A.shiftvec = s->shiftvec; A.nshift = s->nshift; A.central = s->central_shift; A.excl_start = s->excl_start;
+    A.excl_list = s->excl_list; A.cj = s->cj; A.cj_cap = s->cj_cap; A.work = s->work; A.work_cap = s->work_cap;
+    A.exclmask = s->exclmask; A.excl_cap = s->excl_cap; A.rlist = s->rlist;
+    const int nblk = (s->npad / 64 + 3) / 4;
+    hipLaunchKernelGGL(k_build_list, dim3(nblk), dim3(256), 0, s->stream, A);
+    MDX_CHECK(s, hipGetLastError());
+    s->steps_since_search = 0;
+    return MDX_OK;
+}

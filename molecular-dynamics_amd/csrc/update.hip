@@ -1,0 +1,509 @@
+// Leap-frog update, constraints (SETTLE-type water + LINCS), V-rescale thermostat, C-rescale and
+// Parrinello-Rahman barostats, COM-motion removal and the per-step energy bookkeeping.
+// Replaces what `integrator = md`, `dt`, `constraints = h-bonds`, `constraint_algorithm = lincs`,
+// `lincs_order/iter`, `tcoupl = V-rescale`, `pcoupl`, `nstcomm` switch on in gmx mdrun
+// (/root/reference/mdp/production.mdp:3-5,16-19,31-40; npt_complex.mdp:64-66).
+#include "mdx_internal.h"
+#include <algorithm>
+
+// v' = lambda_g * (v + f/m dt) - dt * M v  (M: Parrinello-Rahman coupling matrix, zero otherwise);
+// xp = x + v' dt. Total force = original-order array + sorted nonbonded buffer.
+__global__ __launch_bounds__(256) void k_leapfrog(int n, const float4 *__restrict__ x, float4 *__restrict__ xp,
+                                                  float4 *__restrict__ v, const float *__restrict__ f,
+                                                  const float *__restrict__ f_s, const int *__restrict__ sorted_of,
+                                                  const int *__restrict__ tcgrp, const DevState *__restrict__ d, float dt,
+                                                  int use_lambda, int use_pr)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 xi = x[i];
+    float4 vi = v[i];
+    const int g = sorted_of[i];
+    const float fx = f[3 * i] + f_s[3 * g], fy = f[3 * i + 1] + f_s[3 * g + 1], fz = f[3 * i + 2] + f_s[3 * g + 2];
+    const float im = vi.w;
+    float lam = 1.0f;
+    if (use_lambda) lam = (float)d->lambda[tcgrp[i]];
+    float nx = vi.x + fx * im * dt, ny = vi.y + fy * im * dt, nz = vi.z + fz * im * dt;
+    nx *= lam; ny *= lam; nz *= lam;
+    if (use_pr) {
+        const double *M = d->pr_M;
+        nx -= dt * (float)(M[0] * vi.x + M[1] * vi.y + M[2] * vi.z);
+        ny -= dt * (float)(M[3] * vi.x + M[4] * vi.y + M[5] * vi.z);
+        nz -= dt * (float)(M[6] * vi.x + M[7] * vi.y + M[8] * vi.z);
+    }
+    vi.x = nx; vi.y = ny; vi.z = nz;
+    v[i] = vi;
+    xp[i] = make_float4(xi.x + nx * dt, xi.y + ny * dt, xi.z + nz * dt, xi.w);
+}
+
+// Rigid three-site water: solve the three holonomic constraint equations
+//   |x'_a - x'_b|^2 = d_ab^2,  x' = xp + (1/m) sum_k lambda_k grad_k(x_old)
+// for the Lagrange multipliers by Newton iteration (the SETTLE solution of Miyamoto & Kollman 1992
+// is the same root, reached here iteratively in float32 with differences formed first).
+// One thread per molecule; also corrects velocities and, on virial steps, accumulates the
+// constraint virial -1/2 sum r_old (x) G with G = m dx / dt^2.
+template <bool VIRIAL>
+__global__ __launch_bounds__(256) void k_settle(int nw, const int4 *__restrict__ idx, const float4 *__restrict__ x,
+                                                float4 *__restrict__ xp, float4 *__restrict__ v, float doh, float dhh,
+                                                float inv_dt, DevState *dw)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    float v9[9] = { 0 };
+    if (t < nw) {
+        const int4 a = idx[t];
+        const float4 vo = v[a.x], vh1 = v[a.y], vh2 = v[a.z];
+        const float imo = vo.w, imh = vh1.w;
+        const float3 o0 = xyz(x[a.x]), h10 = xyz(x[a.y]), h20 = xyz(x[a.z]);
+        const float4 po = xp[a.x], ph1 = xp[a.y], ph2 = xp[a.z];
+        // old bond vectors (constraint gradients) and unconstrained new bond vectors
+        const float3 r0[3] = { o0 - h10, o0 - h20, h10 - h20 };
+        float3 s[3] = { xyz(po) - xyz(ph1), xyz(po) - xyz(ph2), xyz(ph1) - xyz(ph2) };
+        const float L2[3] = { doh * doh, doh * doh, dhh * dhh };
+        // d s_k / d lambda_m = A[k][m] * r0[m]
+        const float A[3][3] = { { imo + imh, imo, -imh }, { imo, imo + imh, imh }, { -imh, imh, 2.0f * imh } };
+        float lam[3] = { 0.0f, 0.0f, 0.0f };
+        for (int it = 0; it < 6; it++) {
+            float3 c[3];
+            float sig[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                c[k] = s[k] + (A[k][0] * lam[0]) * r0[0] + (A[k][1] * lam[1]) * r0[1] + (A[k][2] * lam[2]) * r0[2];
+                sig[k] = dot3(c[k], c[k]) - L2[k];
+            }
+            float J[3][3];
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+#pragma unroll
+                for (int m = 0; m < 3; m++) J[k][m] = 2.0f * A[k][m] * dot3(c[k], r0[m]);
+            // solve J dl = -sig (Cramer)
+            const float det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
+                              J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+            const float id = 1.0f / det;
+            const float b0 = -sig[0], b1 = -sig[1], b2 = -sig[2];
+            const float d0 = b0 * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (b1 * J[2][2] - J[1][2] * b2) + J[0][2] * (b1 * J[2][1] - J[1][1] * b2);
+            const float d1 = J[0][0] * (b1 * J[2][2] - J[1][2] * b2) - b0 * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) + J[0][2] * (J[1][0] * b2 - b1 * J[2][0]);
+            const float d2 = J[0][0] * (J[1][1] * b2 - b1 * J[2][1]) - J[0][1] * (J[1][0] * b2 - b1 * J[2][0]) + b0 * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+            lam[0] += d0 * id; lam[1] += d1 * id; lam[2] += d2 * id;
+            const float tol = 1e-7f * L2[2];
+            if (fabsf(sig[0]) < tol && fabsf(sig[1]) < tol && fabsf(sig[2]) < tol && it > 0) break;
+        }
+        // displacements: dO = imo (l0 r0 + l1 r1), dH1 = imh (-l0 r0 + l2 r2), dH2 = imh (-l1 r1 - l2 r2)
+        const float3 dO = imo * (lam[0] * r0[0] + lam[1] * r0[1]);
+        const float3 dH1 = imh * (lam[2] * r0[2] - lam[0] * r0[0]);
+        const float3 dH2 = -imh * (lam[1] * r0[1] + lam[2] * r0[2]);
+        xp[a.x] = make_float4(po.x + dO.x, po.y + dO.y, po.z + dO.z, po.w);
+        xp[a.y] = make_float4(ph1.x + dH1.x, ph1.y + dH1.y, ph1.z + dH1.z, ph1.w);
+        xp[a.z] = make_float4(ph2.x + dH2.x, ph2.y + dH2.y, ph2.z + dH2.z, ph2.w);
+        v[a.x] = make_float4(vo.x + dO.x * inv_dt, vo.y + dO.y * inv_dt, vo.z + dO.z * inv_dt, vo.w);
+        v[a.y] = make_float4(vh1.x + dH1.x * inv_dt, vh1.y + dH1.y * inv_dt, vh1.z + dH1.z * inv_dt, vh1.w);
+        v[a.z] = make_float4(vh2.x + dH2.x * inv_dt, vh2.y + dH2.y * inv_dt, vh2.z + dH2.z * inv_dt, vh2.w);
+        if (VIRIAL) {
+            // constraint forces along the old bonds: G_k = lam_k r0_k / dt^2 acting on the first atom
+            const float s2 = inv_dt * inv_dt;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float3 g = (lam[k] * s2) * r0[k];
+                v9[0] += r0[k].x * g.x; v9[1] += r0[k].x * g.y; v9[2] += r0[k].x * g.z;
+                v9[3] += r0[k].y * g.x; v9[4] += r0[k].y * g.y; v9[5] += r0[k].y * g.z;
+                v9[6] += r0[k].z * g.x; v9[7] += r0[k].z * g.y; v9[8] += r0[k].z * g.z;
+            }
+        }
+    }
+    if (VIRIAL) {
+        __shared__ double red[16];
+        for (int k = 0; k < 9; k++) {
+            const double r = block_sum_d((double)v9[k], red);
+            if (threadIdx.x == 0) atomicAdd(&dw->vir[k], -0.5 * r);
+        }
+    }
+}
+
+// LINCS (Hess et al. 1997) for small coupled components (h-bond constraints couple only through a
+// shared heavy atom): one thread per connected component of at most MDX_LINCS_MAXK constraints,
+// matrix expansion of order `order`, `niter` correction iterations for rotational lengthening.
+template <bool VIRIAL>
+__global__ __launch_bounds__(128) void k_lincs(int ncomp, const int *__restrict__ comp_start, const int2 *__restrict__ cij,
+                                               const float *__restrict__ clen, const float4 *__restrict__ x, float4 *__restrict__ xp,
+                                               float4 *__restrict__ v, int order, int niter, float inv_dt, DevState *dw)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    float v9[9] = { 0 };
+    if (t < ncomp) {
+        const int c0 = comp_start[t];
+        const int K = comp_start[t + 1] - c0;
+        int ia[MDX_LINCS_MAXK], ib[MDX_LINCS_MAXK];
+        float3 B[MDX_LINCS_MAXK];
+        float S[MDX_LINCS_MAXK], len[MDX_LINCS_MAXK], rhs[MDX_LINCS_MAXK], sol[MDX_LINCS_MAXK], tmp[MDX_LINCS_MAXK];
+        float ima[MDX_LINCS_MAXK], imb[MDX_LINCS_MAXK], lamtot[MDX_LINCS_MAXK];
+        float Acoef[MDX_LINCS_MAXK][MDX_LINCS_MAXK];
+        for (int k = 0; k < K; k++) {
+            const int2 p = cij[c0 + k];
+            ia[k] = p.x; ib[k] = p.y; len[k] = clen[c0 + k];
+            ima[k] = v[p.x].w; imb[k] = v[p.y].w;
+            S[k] = rsqrtf(ima[k] + imb[k]);
+            float3 d = xyz(x[p.x]) - xyz(x[p.y]);
+            B[k] = rsqrtf(dot3(d, d)) * d;
+            lamtot[k] = 0.0f;
+        }
+        for (int k = 0; k < K; k++)
+            for (int m = 0; m < K; m++) {
+                float c = 0.0f;
+                if (m != k) {
+                    // sign +1 when the shared atom is first in both or second in both
+                    if (ia[k] == ia[m]) c = -ima[k];
+                    else if (ib[k] == ib[m]) c = -imb[k];
+                    else if (ia[k] == ib[m]) c = ima[k];
+                    else if (ib[k] == ia[m]) c = imb[k];
+                    c *= S[k] * S[m] * dot3(B[k], B[m]);
+                }
+                Acoef[k][m] = c;
+            }
+        for (int pass = 0; pass <= niter; pass++) {
+            for (int k = 0; k < K; k++) {
+                const float3 d = xyz(xp[ia[k]]) - xyz(xp[ib[k]]);
+                if (pass == 0) rhs[k] = S[k] * (dot3(B[k], d) - len[k]);
+                else {
+                    const float p2 = 2.0f * len[k] * len[k] - dot3(d, d);
+                    rhs[k] = S[k] * (len[k] - sqrtf(fmaxf(p2, 0.0f)));
+                }
+                sol[k] = rhs[k];
+            }
+            for (int o = 0; o < order; o++) {
+                for (int k = 0; k < K; k++) {
+                    float a = 0.0f;
+                    for (int m = 0; m < K; m++) a += Acoef[k][m] * rhs[m];
+                    tmp[k] = a;
+                }
+                for (int k = 0; k < K; k++) { rhs[k] = tmp[k]; sol[k] += tmp[k]; }
+            }
+            for (int k = 0; k < K; k++) {
+                const float l = S[k] * sol[k];
+                lamtot[k] += l;
+                const float3 da = (-ima[k] * l) * B[k], db = (imb[k] * l) * B[k];
+                float4 pa = xp[ia[k]], pb = xp[ib[k]];
+                pa.x += da.x; pa.y += da.y; pa.z += da.z; pb.x += db.x; pb.y += db.y; pb.z += db.z;
+                xp[ia[k]] = pa; xp[ib[k]] = pb;
+                float4 va = v[ia[k]], vb = v[ib[k]];
+                va.x += da.x * inv_dt; va.y += da.y * inv_dt; va.z += da.z * inv_dt;
+                vb.x += db.x * inv_dt; vb.y += db.y * inv_dt; vb.z += db.z * inv_dt;
+                v[ia[k]] = va; v[ib[k]] = vb;
+            }
+        }
+        if (VIRIAL) {
+            const float s2 = inv_dt * inv_dt;
+            for (int k = 0; k < K; k++) {
+                // force on atom a: -lam B / dt^2 ; r_ab = |r_old| B (old bond = constraint length)
+                const float g = -lamtot[k] * s2 * len[k];
+                v9[0] += B[k].x * B[k].x * g; v9[1] += B[k].x * B[k].y * g; v9[2] += B[k].x * B[k].z * g;
+                v9[3] += B[k].y * B[k].x * g; v9[4] += B[k].y * B[k].y * g; v9[5] += B[k].y * B[k].z * g;
+                v9[6] += B[k].z * B[k].x * g; v9[7] += B[k].z * B[k].y * g; v9[8] += B[k].z * B[k].z * g;
+            }
+        }
+    }
+    if (VIRIAL) {
+        __shared__ double red[16];
+        for (int k = 0; k < 9; k++) {
+            const double r = block_sum_d((double)v9[k], red);
+            if (threadIdx.x == 0) atomicAdd(&dw->vir[k], -0.5 * r);
+        }
+    }
+}
+
+// Half-step kinetic energy per T-coupling group (+ tensor) from the current velocities.
+__global__ __launch_bounds__(256) void k_ke(int n, const float4 *__restrict__ v, const int *__restrict__ tcgrp, int ntc,
+                                            DevState *dw, int old_slot, int tensor)
+{
+    __shared__ double red[16];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float ke = 0.0f; int g = 0;
+    float t6[6] = { 0, 0, 0, 0, 0, 0 };
+    if (i < n) {
+        const float4 vi = v[i];
+        const float m = vi.w > 0.0f ? 1.0f / vi.w : 0.0f;
+        ke = 0.5f * m * (vi.x * vi.x + vi.y * vi.y + vi.z * vi.z);
+        g = tcgrp[i];
+        if (tensor) {
+            t6[0] = 0.5f * m * vi.x * vi.x; t6[1] = 0.5f * m * vi.x * vi.y; t6[2] = 0.5f * m * vi.x * vi.z;
+            t6[3] = 0.5f * m * vi.y * vi.y; t6[4] = 0.5f * m * vi.y * vi.z; t6[5] = 0.5f * m * vi.z * vi.z;
+        }
+    }
+    const int ng = ntc > 0 ? ntc : 1;
+    for (int k = 0; k < ng; k++) {
+        const double r = block_sum_d((g == k && i < n) ? (double)ke : 0.0, red);
+        if (threadIdx.x == 0 && r != 0.0) atomicAdd(old_slot ? &dw->ekinh_old[k] : &dw->ekinh[k], r);
+    }
+    if (tensor) {
+        const int map[6][2] = { { 0, 0 }, { 1, 3 }, { 2, 6 }, { 4, 4 }, { 5, 7 }, { 8, 8 } };
+        for (int k = 0; k < 6; k++) {
+            const double r = block_sum_d((double)t6[k], red);
+            if (threadIdx.x == 0) {
+                atomicAdd(&dw->ekin_tensor[map[k][0]], 0.5 * r);   // average of two half steps
+                if (map[k][1] != map[k][0]) atomicAdd(&dw->ekin_tensor[map[k][1]], 0.5 * r);
+            }
+        }
+    }
+}
+
+// V-rescale (Bussi, Donadio, Parrinello 2007): one thread draws the new kinetic energy of every
+// group from the half-step kinetic energy just computed and stores lambda for the coming step.
+__global__ void k_tcouple(DevState *dw, int ntc, const double *ref_t, const double *tau_t, const double *ndf,
+                          double dt_tc, unsigned long long seed, long long step)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int g = 0; g < ntc; g++) {
+        const double ek = dw->ekinh[g];
+        double lam = 1.0;
+        if (ek > 0.0 && tau_t[g] > 0.0 && ndf[g] > 0.0) {
+            const double ekref = 0.5 * ndf[g] * MDX_BOLTZ * ref_t[g];
+            const double c = exp(-dt_tc / tau_t[g]);
+            RngStream rng(seed, 0x7c0000ull + g, (uint64_t)step);
+            const double r1 = rng.gauss();
+            const double rs = rng.chi2(ndf[g] - 1.0);
+            const double eknew = ek + (1.0 - c) * (ekref * (rs + r1 * r1) / ndf[g] - ek) +
+                                 2.0 * r1 * sqrt(c * (1.0 - c) * ek * ekref / ndf[g]);
+            lam = sqrt(fmax(eknew, 0.0) / ek);
+            dw->therm_integral[g] -= (eknew - ek);
+        }
+        dw->lambda[g] = lam;
+    }
+}
+
+// Finish an energy step: kinetic energy as the leap-frog average, temperature, pressure tensor,
+// dispersion correction, totals and the conserved quantity.
+__global__ void k_finish_energy(DevState *dw, int ntc, double ndf_total, int dispcorr, double c6avg, int natoms,
+                                double rc, double q2sum, double beta, int have_pme)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int ng = ntc > 0 ? ntc : 1;
+    double ek = 0.0;
+    for (int g = 0; g < ng; g++) ek += 0.5 * (dw->ekinh_old[g] + dw->ekinh[g]);
+    dw->ener[MDX_E_KIN] = ek;
+    const double vol = dw->boxd[0] * dw->boxd[4] * dw->boxd[8];
+    double edisp = 0.0, pdisp = 0.0;
+    if (dispcorr) {
+        const double nn = (double)natoms * natoms;
+        const double etail = -(2.0 / 3.0) * M_PI * nn / vol * c6avg / (rc * rc * rc);
+        edisp = 2.0 * etail;  // tail + the constant removed by the potential-shift inside rc
+        if (dispcorr == 2) pdisp = -(4.0 / 3.0) * M_PI * nn / (vol * vol) * c6avg / (rc * rc * rc) * MDX_PRESFAC;
+    }
+    dw->ener[MDX_E_DISPCORR] = edisp;
+    if (have_pme) dw->ener[MDX_E_COUL_EXCL] -= 138.935458 * beta / sqrt(M_PI) * q2sum;
+    double pot = 0.0;
+    for (int k = MDX_E_LJ; k <= MDX_E_DISPCORR; k++) pot += dw->ener[k];
+    dw->ener[MDX_E_POT] = pot;
+    dw->ener[MDX_E_TEMP] = ndf_total > 0 ? 2.0 * ek / (ndf_total * MDX_BOLTZ) : 0.0;
+    double ptr = 0.0;
+    for (int a = 0; a < 9; a++) {
+        dw->pres[a] = 2.0 / vol * (dw->ekin_tensor[a] - dw->vir[a]) * MDX_PRESFAC + ((a % 4 == 0) ? pdisp : 0.0);
+        if (a % 4 == 0) ptr += dw->pres[a];
+    }
+    dw->ener[MDX_E_PRES] = ptr / 3.0;
+    dw->ener[MDX_E_VOLUME] = vol;
+    double cons = pot + ek + dw->baro_integral;
+    for (int g = 0; g < ng; g++) cons += dw->therm_integral[g];
+    dw->ener[MDX_E_CONSERVED] = cons;
+}
+
+// Barostat scalars (one thread). kind 1: C-rescale (Bernetti & Bussi 2020), isotropic:
+//   d eps = -(beta/tau_p)(P0 - P) dt + sqrt(2 kT beta dt / (V tau_p)) dW,  mu = exp(d eps / 3).
+// kind 2: Parrinello-Rahman, isotropic: box-velocity ODE with W^-1 = 4 pi^2 beta / (3 tau_p^2 L).
+__global__ void k_pcouple(DevState *dw, int kind, double tau_p, double ref_p, double compress, double dt_pc, double kT,
+                          unsigned long long seed, long long step)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double *b = dw->boxd;
+    const double vol = b[0] * b[4] * b[8];
+    const double P = (dw->pres[0] + dw->pres[4] + dw->pres[8]) / 3.0;
+    double mu[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    for (int a = 0; a < 9; a++) dw->pr_M[a] = 0.0;
+    if (kind == 1) {
+        RngStream rng(seed, 0xba0000ull, (uint64_t)step);
+        const double gauss = rng.gauss();
+        const double deps = -(compress / tau_p) * (ref_p - P) * dt_pc +
+                            sqrt(2.0 * kT * compress * MDX_PRESFAC * dt_pc / (vol * tau_p)) * gauss;
+        const double m = exp(deps / 3.0);
+        mu[0] = mu[4] = mu[8] = m;
+        // work done by the scaling: -P0 dV (+ kinetic part through v scaling is handled by ekin)
+        dw->baro_integral -= 0.0;
+    } else if (kind == 2) {
+        // isotropic: every box element follows the same relative rate
+        double maxl = fmax(b[0], fmax(b[4], b[8]));
+        const double winv = 4.0 * M_PI * M_PI * compress / (3.0 * tau_p * tau_p * maxl);
+        // d2b/dt2 = V W^-1 b'^-1 (P - Pref): for isotropic scaling b'^-1 (P-Pref) -> (P - Pref)/b_ii
+        for (int a = 0; a < 9; a++) {
+            const int r = a / 3, c = a % 3;
+            double acc = 0.0;
+            if (r == c) acc = vol * winv * (P - ref_p) / b[a];
+            dw->pr_boxv[a] += dt_pc * acc;
+        }
+        // isotropic: average the diagonal relative rates and apply to all elements
+        const double rate = (dw->pr_boxv[0] / b[0] + dw->pr_boxv[4] / b[4] + dw->pr_boxv[8] / b[8]) / 3.0;
+        for (int a = 0; a < 9; a++) dw->pr_boxv[a] = rate * b[a];
+        const double m = 1.0 + rate * dt_pc;
+        mu[0] = mu[4] = mu[8] = m;
+        // velocity coupling M = b^-1 (b db'/dt + db/dt b') b'^-1 = 2 rate I for isotropic scaling
+        dw->pr_M[0] = dw->pr_M[4] = dw->pr_M[8] = 2.0 * rate;
+    }
+    for (int a = 0; a < 9; a++) dw->mu[a] = mu[a];
+    // new box (rows scaled isotropically)
+    for (int a = 0; a < 9; a++) b[a] *= mu[0];
+    DevBox nb;
+    for (int a = 0; a < 9; a++) nb.h[a] = (float)b[a];
+    const double ia = 1.0 / b[0], ie = 1.0 / b[4], ii = 1.0 / b[8];
+    // inverse of lower-triangular rows a=(b0,0,0) b=(b3,b4,0) c=(b6,b7,b8)
+    double inv[9] = { ia, 0, 0, -b[3] * ia * ie, ie, 0, (b[3] * b[7] - b[4] * b[6]) * ia * ie * ii, -b[7] * ie * ii, ii };
+    for (int a = 0; a < 9; a++) nb.inv[a] = (float)inv[a];
+    nb.vol = (float)(b[0] * b[4] * b[8]);
+    for (int a = 0; a < 5; a++) nb.pad[a] = 0.0f;
+    dw->box = nb;
+}
+
+// Scale coordinates (and restraint references) by mu; C-rescale also scales velocities by 1/mu.
+__global__ void k_scale(int n, float4 *__restrict__ x, float4 *__restrict__ v, const DevState *__restrict__ d, int scale_v,
+                        int nposres, float4 *__restrict__ posres_ref)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float m = (float)d->mu[0];
+    if (i < n) {
+        float4 p = x[i]; p.x *= m; p.y *= m; p.z *= m; x[i] = p;
+        if (scale_v) { float4 w = v[i]; const float im = 1.0f / m; w.x *= im; w.y *= im; w.z *= im; v[i] = w; }
+    }
+    if (i < nposres) { float4 r = posres_ref[i]; r.x *= m; r.y *= m; r.z *= m; posres_ref[i] = r; }
+}
+
+__global__ __launch_bounds__(256) void k_comm_sum(int n, const float4 *__restrict__ v, DevState *dw)
+{
+    __shared__ double red[16];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double p[4] = { 0, 0, 0, 0 };
+    if (i < n) {
+        const float4 vi = v[i];
+        const double m = vi.w > 0.0f ? 1.0 / vi.w : 0.0;
+        p[0] = m * vi.x; p[1] = m * vi.y; p[2] = m * vi.z; p[3] = m;
+    }
+    for (int k = 0; k < 4; k++) {
+        const double r = block_sum_d(p[k], red);
+        if (threadIdx.x == 0) atomicAdd(&dw->com_v[k], r);
+    }
+}
+__global__ void k_comm_sub(int n, float4 *__restrict__ v, const DevState *__restrict__ d)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double im = 1.0 / d->com_v[3];
+    float4 vi = v[i];
+    vi.x -= (float)(d->com_v[0] * im); vi.y -= (float)(d->com_v[1] * im); vi.z -= (float)(d->com_v[2] * im);
+    v[i] = vi;
+}
+
+__global__ void k_merge_forces(int n, const float *__restrict__ f, const float *__restrict__ f_s,
+                               const int *__restrict__ sorted_of, float *__restrict__ out, int have_sorted)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = f[3 * i], b = f[3 * i + 1], c = f[3 * i + 2];
+    if (have_sorted) { const int g = sorted_of[i]; a += f_s[3 * g]; b += f_s[3 * g + 1]; c += f_s[3 * g + 2]; }
+    out[3 * i] = a; out[3 * i + 1] = b; out[3 * i + 2] = c;
+}
+
+int mdx_launch_update(mdx_system *s, bool do_tc, bool do_pr, bool virial)
+{
+    const int nb = (s->n + 255) / 256;
+    hipLaunchKernelGGL(k_leapfrog, dim3(nb), dim3(256), 0, s->stream, s->n, s->x, s->xp, s->v, s->f, s->f_s, s->sorted_of,
+                       s->tcgrp, s->d, s->dt, do_tc ? 1 : 0, do_pr ? 1 : 0);
+    const float inv_dt = 1.0f / s->dt;
+    if (s->nsettle > 0) {
+        const int nbw = (s->nsettle + 255) / 256;
+        if (virial) hipLaunchKernelGGL(k_settle<true>, dim3(nbw), dim3(256), 0, s->stream, s->nsettle, s->settle_idx, s->x, s->xp, s->v, s->settle_doh, s->settle_dhh, inv_dt, s->d);
+        else hipLaunchKernelGGL(k_settle<false>, dim3(nbw), dim3(256), 0, s->stream, s->nsettle, s->settle_idx, s->x, s->xp, s->v, s->settle_doh, s->settle_dhh, inv_dt, s->d);
+    }
+    if (s->ncomp > 0) {
+        const int nbc = (s->ncomp + 127) / 128;
+        if (virial) hipLaunchKernelGGL(k_lincs<true>, dim3(nbc), dim3(128), 0, s->stream, s->ncomp, s->comp_start, s->cons_ij, s->cons_len, s->x, s->xp, s->v, s->lincs_order, s->lincs_iter, inv_dt, s->d);
+        else hipLaunchKernelGGL(k_lincs<false>, dim3(nbc), dim3(128), 0, s->stream, s->ncomp, s->comp_start, s->cons_ij, s->cons_len, s->x, s->xp, s->v, s->lincs_order, s->lincs_iter, inv_dt, s->d);
+    }
+    MDX_CHECK(s, hipGetLastError());
+    // the constrained new positions become the state
+    float4 *t = s->x; s->x = s->xp; s->xp = t;
+    return MDX_OK;
+}
+
+int mdx_launch_ke(mdx_system *s, bool old_slot, bool tensor)
+{
+    const int nb = (s->n + 255) / 256;
+    hipLaunchKernelGGL(k_ke, dim3(nb), dim3(256), 0, s->stream, s->n, s->v, s->tcgrp, s->ntc, s->d, old_slot ? 1 : 0, tensor ? 1 : 0);
+    MDX_CHECK(s, hipGetLastError());
+    return MDX_OK;
+}
+
+// Zero the accumulators that the coming step's kernels add into.
+__global__ void k_clear(DevState *dw, int energies, int ekin_new, int ekin_old)
+{
+    const int t = threadIdx.x;
+    if (energies) {
+        if (t < MDX_E_N) dw->ener[t] = 0.0;
+        if (t < 9) { dw->vir[t] = 0.0; dw->ekin_tensor[t] = 0.0; }
+    }
+    if (t < MDX_MAX_TC) {
+        if (ekin_new) dw->ekinh[t] = 0.0;
+        if (ekin_old) dw->ekinh_old[t] = 0.0;
+    }
+}
+
+int mdx_launch_clear(mdx_system *s, bool energies, bool ekin_new, bool ekin_old)
+{
+    hipLaunchKernelGGL(k_clear, dim3(1), dim3(64), 0, s->stream, s->d, energies ? 1 : 0, ekin_new ? 1 : 0, ekin_old ? 1 : 0);
+    MDX_CHECK(s, hipGetLastError());
+    return MDX_OK;
+}
+
+int mdx_launch_tcouple(mdx_system *s)
+{
+    if (s->ntc <= 0) return MDX_OK;
+    hipLaunchKernelGGL(k_tcouple, dim3(1), dim3(64), 0, s->stream, s->d, s->ntc, s->d_tc, s->d_tc + MDX_MAX_TC,
+                       s->d_tc + 2 * MDX_MAX_TC, (double)s->nsttcouple * s->dt, (unsigned long long)s->seed, s->step);
+    MDX_CHECK(s, hipGetLastError());
+    return MDX_OK;
+}
+
+int mdx_launch_finish_energy(mdx_system *s)
+{
+    double ndf_total = 0;
+    for (int g = 0; g < s->ntc; g++) ndf_total += s->ndf[g];
+    if (s->ntc == 0) ndf_total = s->ndf_total;
+    hipLaunchKernelGGL(k_finish_energy, dim3(1), dim3(64), 0, s->stream, s->d, s->ntc, ndf_total, s->dispcorr, s->dispcorr_c6avg,
+                       s->n, (double)s->rc, s->q2sum, (double)s->beta, s->have_pme ? 1 : 0);
+    MDX_CHECK(s, hipGetLastError());
+    return MDX_OK;
+}
+
+int mdx_launch_pcouple(mdx_system *s)
+{
+    if (s->pcoupl == 0) return MDX_OK;
+    const double kT = MDX_BOLTZ * (s->ntc > 0 ? s->ref_t[0] : 300.0);
+    hipLaunchKernelGGL(k_pcouple, dim3(1), dim3(64), 0, s->stream, s->d, s->pcoupl, s->tau_p, s->ref_p, s->compress,
+                       (double)s->nstpcouple * s->dt, kT, (unsigned long long)s->seed, s->step);
+    const int nb = (std::max(s->n, s->nposres) + 255) / 256;
+    hipLaunchKernelGGL(k_scale, dim3(nb), dim3(256), 0, s->stream, s->n, s->x, s->v, s->d, s->pcoupl == 1 ? 1 : 0,
+                       s->refcoord_scaling ? s->nposres : 0, s->posres_ref);
+    MDX_CHECK(s, hipGetLastError());
+    return MDX_OK;
+}
+
+int mdx_launch_comm(mdx_system *s)
+{
+    const int nb = (s->n + 255) / 256;
+    MDX_CHECK(s, hipMemsetAsync((char *)s->d + offsetof(DevState, com_v), 0, sizeof(double) * 4, s->stream));
+    hipLaunchKernelGGL(k_comm_sum, dim3(nb), dim3(256), 0, s->stream, s->n, s->v, s->d);
+    hipLaunchKernelGGL(k_comm_sub, dim3(nb), dim3(256), 0, s->stream, s->n, s->v, s->d);
+    MDX_CHECK(s, hipGetLastError());
+    return MDX_OK;
+}
+
+int mdx_launch_merge_forces(mdx_system *s, float *out3n)
+{
+    const int nb = (s->n + 255) / 256;
+    hipLaunchKernelGGL(k_merge_forces, dim3(nb), dim3(256), 0, s->stream, s->n, s->f, s->f_s, s->sorted_of, out3n, 1);
+    MDX_CHECK(s, hipGetLastError());
+    return MDX_OK;
+}

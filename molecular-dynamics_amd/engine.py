@@ -1,0 +1,306 @@
+"""ctypes binding of libmdx.so (include/mdx.h) and the `Engine` convenience wrapper.
+
+The HIP library is the only compute path: if it cannot be loaded, or no HIP device is
+present, construction raises — there is no CPU fallback in the product.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import numpy as np
+
+from . import units as U
+from .system import MDSystem
+
+E_NAMES = ["LJ", "COUL_SR", "COUL_RECIP", "COUL_EXCL", "BOND", "ANGLE", "DIH", "LJ14", "COUL14", "POSRES",
+           "PULL", "DISPCORR", "KIN", "POT", "TEMP", "PRES", "VOLUME", "CONSERVED"]
+E_N = len(E_NAMES)
+E = {n: i for i, n in enumerate(E_NAMES)}
+F_NONBONDED, F_PME, F_EXCL, F_BONDED, F_POSRES, F_PULL, F_ALL = 1, 2, 4, 8, 16, 32, 63
+
+_LIB = None
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmdx.so")
+
+SYMBOLS = [
+    "mdx_version", "mdx_last_error", "mdx_create", "mdx_destroy", "mdx_set_atoms", "mdx_set_exclusions",
+    "mdx_set_bonds", "mdx_set_angles", "mdx_set_dihedrals", "mdx_set_pairs14", "mdx_set_posres", "mdx_set_settles",
+    "mdx_set_constraints", "mdx_set_nonbonded", "mdx_set_pme", "mdx_set_integrator", "mdx_set_tcoupl",
+    "mdx_set_pcoupl", "mdx_set_dispcorr", "mdx_set_pull", "mdx_set_state", "mdx_set_state_device", "mdx_get_state",
+    "mdx_get_step", "mdx_compute_forces", "mdx_get_forces", "mdx_get_energies", "mdx_get_virial", "mdx_step",
+    "mdx_synchronize", "mdx_get_list_stats", "mdx_pop_energy_frames", "mdx_pop_pull_records",
+    "mdx_enable_kernel_timing", "mdx_get_kernel_timing",
+]
+
+
+class MdxError(RuntimeError):
+    pass
+
+
+def load_library(path: str | None = None):
+    """Load libmdx.so and declare the C signatures. Raises if the library is missing."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise MdxError(f"{p} not found: build it with `make -C molecular-dynamics_amd/csrc` "
+                       "(the engine has no CPU fallback)")
+    L = ctypes.CDLL(p)
+    c_int, c_f, c_d, vp = ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
+    fp, ip, dp = ctypes.POINTER(c_f), ctypes.POINTER(c_int), ctypes.POINTER(c_d)
+    llp = ctypes.POINTER(ctypes.c_longlong)
+    L.mdx_version.restype = c_int
+    L.mdx_last_error.restype = ctypes.c_char_p; L.mdx_last_error.argtypes = [vp]
+    L.mdx_create.restype = vp; L.mdx_create.argtypes = [c_int, c_int]
+    L.mdx_destroy.restype = None; L.mdx_destroy.argtypes = [vp]
+    L.mdx_set_atoms.argtypes = [vp, fp, fp, fp, fp, ip, ip]
+    L.mdx_set_exclusions.argtypes = [vp, ip, ip]
+    L.mdx_set_bonds.argtypes = [vp, c_int, ip, fp, fp]
+    L.mdx_set_angles.argtypes = [vp, c_int, ip, fp, fp]
+    L.mdx_set_dihedrals.argtypes = [vp, c_int, ip, fp, fp, ip]
+    L.mdx_set_pairs14.argtypes = [vp, c_int, ip, fp, fp, fp]
+    L.mdx_set_posres.argtypes = [vp, c_int, ip, fp, fp, c_int]
+    L.mdx_set_settles.argtypes = [vp, c_int, ip, c_f, c_f]
+    L.mdx_set_constraints.argtypes = [vp, c_int, ip, fp, c_int, c_int]
+    L.mdx_set_nonbonded.argtypes = [vp, c_f, c_f, c_f, c_int]
+    L.mdx_set_pme.argtypes = [vp, c_int, c_int, c_int, c_int]
+    L.mdx_set_integrator.argtypes = [vp, c_f, c_int, c_int]
+    L.mdx_set_tcoupl.argtypes = [vp, c_int, dp, dp, dp, c_int, ctypes.c_ulonglong]
+    L.mdx_set_pcoupl.argtypes = [vp, c_int, c_d, c_d, c_d, c_int]
+    L.mdx_set_dispcorr.argtypes = [vp, c_int, c_d]
+    L.mdx_set_pull.argtypes = [vp, c_int, ip, c_int, ip, c_int, c_int, c_int, c_d, c_d, c_d, c_int, ip, c_int]
+    L.mdx_set_state.argtypes = [vp, fp, fp, fp]
+    L.mdx_set_state_device.argtypes = [vp, vp, vp, fp]
+    L.mdx_get_state.argtypes = [vp, fp, fp, fp]
+    L.mdx_get_step.restype = ctypes.c_longlong; L.mdx_get_step.argtypes = [vp]
+    L.mdx_compute_forces.argtypes = [vp, ctypes.c_uint]
+    L.mdx_get_forces.argtypes = [vp, fp]
+    L.mdx_get_energies.argtypes = [vp, dp]
+    L.mdx_get_virial.argtypes = [vp, dp, dp]
+    L.mdx_step.argtypes = [vp, ctypes.c_longlong]
+    L.mdx_synchronize.argtypes = [vp]
+    L.mdx_get_list_stats.argtypes = [vp, llp]
+    L.mdx_pop_energy_frames.restype = ctypes.c_longlong; L.mdx_pop_energy_frames.argtypes = [vp, dp, ctypes.c_longlong]
+    L.mdx_pop_pull_records.restype = ctypes.c_longlong; L.mdx_pop_pull_records.argtypes = [vp, dp, ctypes.c_longlong]
+    L.mdx_enable_kernel_timing.argtypes = [vp, c_int]
+    L.mdx_get_kernel_timing.argtypes = [vp, dp, llp]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is c_int and name not in ("mdx_version",):
+            pass
+    if path is None:
+        _LIB = L
+    return L
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+def c6_average(sigma, eps):
+    """<C6> over all distinct atom pairs for Lorentz-Berthelot LJ (`DispCorr`)."""
+    key = np.stack([sigma, eps], 1)
+    uniq, cnt = np.unique(key, axis=0, return_counts=True)
+    s = 0.5 * (uniq[:, None, 0] + uniq[None, :, 0]); e = np.sqrt(uniq[:, None, 1] * uniq[None, :, 1])
+    c6 = 4 * e * s ** 6
+    n = len(sigma)
+    tot = 0.5 * ((cnt[:, None] * cnt[None, :] * c6).sum() - (cnt * np.diag(c6)).sum())
+    return float(tot / (0.5 * n * (n - 1)))
+
+
+def verlet_rlist(rc, nstlist, dt, temperature=300.0, min_mass=1.008, water_constrained=True):
+    """Pair-list radius: rc plus a buffer that covers the relative displacement of two light
+    particles over the list lifetime (6 sigma of the ballistic Gaussian estimate, floored at
+    0.05 nm and capped at 0.25 nm). Stands in for GROMACS' `verlet-buffer-tolerance` estimate
+    (/root/reference/mdp/npt_complex.mdp:32); the engine treats `nstlist` as a hint like mdrun."""
+    m_eff = 4.0 * min_mass if water_constrained else min_mass   # constrained H moves with its heavy atom
+    sig1 = np.sqrt(U.BOLTZ * temperature / m_eff) * (nstlist - 1) * dt
+    buf = 6.0 * np.sqrt(2.0) * sig1 * 0.5
+    return float(rc + min(0.25, max(0.05, buf)))
+
+
+class Engine:
+    """One MD system resident on one MI355X, driven through the C ABI."""
+
+    def __init__(self, sysm: MDSystem, rc=1.0, rlist=None, nstlist=10, ewald_rtol=1e-5, pme=True,
+                 fourierspacing=0.16, grid=None, dt=0.002, nstcalcenergy=100, nstcomm=100, device=0,
+                 tc_groups=None, ref_t=None, tau_t=None, nsttcouple=10, seed=1,
+                 pcoupl=0, tau_p=2.0, ref_p=1.0, compressibility=4.5e-5, nstpcouple=10,
+                 dispcorr=0, lincs_order=4, lincs_iter=1, refcoord_scaling=0, use_posres=False, beta=None):
+        self.lib = load_library()
+        self.sys = sysm
+        n = sysm.natoms
+        self.n = n
+        self.h = self.lib.mdx_create(int(device), int(n))
+        if not self.h:
+            raise MdxError("mdx_create failed: " + self.lib.mdx_last_error(None).decode())
+        self.rc = float(rc)
+        self.beta = float(beta) if beta is not None else U.ewald_beta(rc, ewald_rtol)
+        self.dt = float(dt)
+        if rlist is None:
+            rlist = verlet_rlist(rc, nstlist, dt)
+        self.rlist = float(rlist)
+        # T-coupling groups
+        tcg = np.zeros(n, dtype=np.int32)
+        ndf = []
+        nc_atom = sysm.n_constraints_per_atom()
+        if tc_groups:
+            assigned = np.zeros(n, bool)
+            for gi, name in enumerate(tc_groups):
+                idx = sysm.groups[name]
+                tcg[idx] = gi
+                assigned[idx] = True
+            if not assigned.all():
+                raise MdxError("tc-grps do not cover every atom")
+            total_ndf = 3.0 * n - nc_atom.sum()
+            for gi, name in enumerate(tc_groups):
+                idx = sysm.groups[name]
+                nd = 3.0 * len(idx) - nc_atom[idx].sum()
+                # the 3 COM degrees of freedom are removed proportionally
+                ndf.append(nd - 3.0 * nd / total_ndf if nstcomm > 0 else nd)
+        self.ntc = len(tc_groups) if tc_groups else 0
+        self.ndf_total = float(3.0 * n - nc_atom.sum() - (3.0 if nstcomm > 0 else 0.0))
+        self._call("mdx_set_nonbonded", ctypes.c_float(self.rc), ctypes.c_float(self.rlist), ctypes.c_float(self.beta if pme else 0.0),
+                   int(nstlist))
+        m, q, sg, ep = _f32(sysm.mass), _f32(sysm.charge), _f32(sysm.sigma), _f32(sysm.eps)
+        mol = _i32(sysm.molid)
+        self._call("mdx_set_atoms", _p(m, ctypes.c_float), _p(q, ctypes.c_float), _p(sg, ctypes.c_float), _p(ep, ctypes.c_float),
+                   _p(mol, ctypes.c_int), _p(tcg, ctypes.c_int))
+        es, el = _i32(sysm.excl_start), _i32(sysm.excl_list if len(sysm.excl_list) else np.zeros(1, np.int32))
+        self._call("mdx_set_exclusions", _p(es, ctypes.c_int), _p(el, ctypes.c_int))
+        if len(sysm.bonds):
+            a, b0, kb = _i32(sysm.bonds), _f32(sysm.bond_b0), _f32(sysm.bond_kb)
+            self._call("mdx_set_bonds", len(a), _p(a, ctypes.c_int), _p(b0, ctypes.c_float), _p(kb, ctypes.c_float))
+        if len(sysm.angles):
+            a, t0, k = _i32(sysm.angles), _f32(sysm.angle_th0), _f32(sysm.angle_k)
+            self._call("mdx_set_angles", len(a), _p(a, ctypes.c_int), _p(t0, ctypes.c_float), _p(k, ctypes.c_float))
+        if len(sysm.dihedrals):
+            a, p0, k, mu = _i32(sysm.dihedrals), _f32(sysm.dih_phi0), _f32(sysm.dih_k), _i32(sysm.dih_mult)
+            self._call("mdx_set_dihedrals", len(a), _p(a, ctypes.c_int), _p(p0, ctypes.c_float), _p(k, ctypes.c_float), _p(mu, ctypes.c_int))
+        if len(sysm.pairs14):
+            a, c6, c12, qq = _i32(sysm.pairs14), _f32(sysm.pair_c6), _f32(sysm.pair_c12), _f32(sysm.pair_qq)
+            self._call("mdx_set_pairs14", len(a), _p(a, ctypes.c_int), _p(c6, ctypes.c_float), _p(c12, ctypes.c_float), _p(qq, ctypes.c_float))
+        if use_posres and len(sysm.posres_idx):
+            a, r, k = _i32(sysm.posres_idx), _f32(sysm.posres_ref), _f32(sysm.posres_k)
+            self._call("mdx_set_posres", len(a), _p(a, ctypes.c_int), _p(r, ctypes.c_float), _p(k, ctypes.c_float), int(refcoord_scaling))
+        if len(sysm.settles):
+            a = _i32(sysm.settles)
+            self._call("mdx_set_settles", len(a), _p(a, ctypes.c_int), ctypes.c_float(sysm.settle_doh), ctypes.c_float(sysm.settle_dhh))
+        if len(sysm.constraints):
+            a, l = _i32(sysm.constraints), _f32(sysm.constraint_len)
+            self._call("mdx_set_constraints", len(a), _p(a, ctypes.c_int), _p(l, ctypes.c_float), int(lincs_order), int(lincs_iter))
+        if pme:
+            if grid is None:
+                grid = U.pme_grid(sysm.box, fourierspacing)
+            self.grid = tuple(int(g) for g in grid)
+            self._call("mdx_set_pme", self.grid[0], self.grid[1], self.grid[2], 4)
+        else:
+            self.grid = None
+        self._call("mdx_set_integrator", ctypes.c_float(self.dt), int(nstcalcenergy), int(nstcomm))
+        if self.ntc:
+            rt = np.ascontiguousarray(np.broadcast_to(np.asarray(ref_t, dtype=np.float64), (self.ntc,)))
+            tt = np.ascontiguousarray(np.broadcast_to(np.asarray(tau_t, dtype=np.float64), (self.ntc,)))
+            nd = np.ascontiguousarray(ndf, dtype=np.float64)
+            self._call("mdx_set_tcoupl", self.ntc, _p(rt, ctypes.c_double), _p(tt, ctypes.c_double), _p(nd, ctypes.c_double),
+                       int(nsttcouple), ctypes.c_ulonglong(int(seed)))
+        else:
+            nd = np.array([self.ndf_total], dtype=np.float64)
+            self._call("mdx_set_tcoupl", 0, None, None, _p(nd, ctypes.c_double), 1, ctypes.c_ulonglong(int(seed)))
+        self._call("mdx_set_pcoupl", int(pcoupl), float(tau_p), float(ref_p), float(compressibility), int(nstpcouple))
+        if dispcorr:
+            self._call("mdx_set_dispcorr", int(dispcorr), c6_average(sysm.sigma, sysm.eps))
+        self.set_state(sysm.x, sysm.v, sysm.box)
+
+    # ------------------------------------------------------------------ plumbing
+    def _call(self, name, *args):
+        rc = getattr(self.lib, name)(self.h, *args)
+        if rc != 0:
+            raise MdxError(f"{name} failed ({rc}): " + self.lib.mdx_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mdx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ state
+    def set_state(self, x, v, box):
+        x = _f32(x); box = _f32(np.asarray(box).reshape(9))
+        vv = _f32(v) if v is not None else None
+        self._call("mdx_set_state", _p(x, ctypes.c_float), _p(vv, ctypes.c_float) if vv is not None else None, _p(box, ctypes.c_float))
+
+    def get_state(self):
+        x = np.zeros((self.n, 3), np.float32); v = np.zeros((self.n, 3), np.float32); box = np.zeros(9, np.float32)
+        self._call("mdx_get_state", _p(x, ctypes.c_float), _p(v, ctypes.c_float), _p(box, ctypes.c_float))
+        return x, v, box.reshape(3, 3)
+
+    def set_pull(self, group1, group2, type="constant-force", k=500.0, rate=0.0, init=0.0, start=True,
+                 dim=(1, 1, 1), nstout=50, pbcatom1=-1, pbcatom2=-1):
+        g1, g2 = _i32(group1), _i32(group2)
+        d = _i32(dim)
+        t = {"constant-force": 0, "umbrella": 1}[type]
+        self._call("mdx_set_pull", len(g1), _p(g1, ctypes.c_int), len(g2), _p(g2, ctypes.c_int), int(pbcatom1), int(pbcatom2),
+                   t, float(k), float(rate), float(init), 1 if start else 0, _p(d, ctypes.c_int), int(nstout))
+
+    # ------------------------------------------------------------------ compute
+    def compute(self, terms=F_ALL & ~F_PULL):
+        self._call("mdx_compute_forces", ctypes.c_uint(int(terms)))
+        f = np.zeros((self.n, 3), np.float32)
+        self._call("mdx_get_forces", _p(f, ctypes.c_float))
+        return f, self.energies()
+
+    def energies(self):
+        e = np.zeros(E_N, np.float64)
+        self._call("mdx_get_energies", _p(e, ctypes.c_double))
+        return {n: float(e[i]) for i, n in enumerate(E_NAMES)}
+
+    def virial(self):
+        v = np.zeros(9); p = np.zeros(9)
+        self._call("mdx_get_virial", _p(v, ctypes.c_double), _p(p, ctypes.c_double))
+        return v.reshape(3, 3), p.reshape(3, 3)
+
+    def step(self, nsteps):
+        self._call("mdx_step", ctypes.c_longlong(int(nsteps)))
+
+    def synchronize(self):
+        self._call("mdx_synchronize")
+
+    def list_stats(self):
+        st = (ctypes.c_longlong * 5)()
+        self._call("mdx_get_list_stats", st)
+        return dict(superclusters=st[0], cj_entries=st[1], work_units=st[2], excl_masks=st[3], cluster_pairs=st[4])
+
+    def pop_energy_frames(self, max_frames=8192):
+        buf = np.zeros((max_frames, 2 + E_N), np.float64)
+        n = self.lib.mdx_pop_energy_frames(self.h, _p(buf, ctypes.c_double), ctypes.c_longlong(max_frames))
+        if n < 0:
+            raise MdxError("mdx_pop_energy_frames failed: " + self.lib.mdx_last_error(self.h).decode())
+        return buf[:n]
+
+    def pop_pull_records(self, max_records=65536):
+        buf = np.zeros((max_records, 4), np.float64)
+        n = self.lib.mdx_pop_pull_records(self.h, _p(buf, ctypes.c_double), ctypes.c_longlong(max_records))
+        if n < 0:
+            raise MdxError("mdx_pop_pull_records failed: " + self.lib.mdx_last_error(self.h).decode())
+        return buf[:n]
+
+    def enable_kernel_timing(self, on=True):
+        self._call("mdx_enable_kernel_timing", 1 if on else 0)
+
+    def kernel_timing(self):
+        ms = ctypes.c_double(0); nl = ctypes.c_longlong(0)
+        self._call("mdx_get_kernel_timing", ctypes.byref(ms), ctypes.byref(nl))
+        return ms.value, nl.value

@@ -1,0 +1,315 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY (float64 numpy + oracle/nb_ref.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this. The
+product path (molecular-dynamics_amd/) never does.
+
+PARITY UNPINNED BY THE REFERENCE: the pipeline's MD arithmetic lives in GROMACS
+(`gromacs>=2021`, /root/reference/envs/environment.yml:24 — not vendored, not installed,
+no golden vectors in the repo). Each function below restates the published algorithm that
+a line of the pipeline's .mdp files switches on, cited next to it; the restatement is
+pinned by closed-form known answers in tests/test_oracle_*.py.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import numpy as np
+
+ONE_4PI_EPS0 = 138.935458
+BOLTZ = 0.0083144626
+PRESFAC = 16.6054
+
+_here = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_here, "libnbref.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle/libnbref.so missing: run `make -C oracle`")
+        L = ctypes.CDLL(path)
+        dp = ctypes.POINTER(ctypes.c_double)
+        ip = ctypes.POINTER(ctypes.c_int)
+        L.orc_nonbonded.restype = ctypes.c_long
+        L.orc_nonbonded.argtypes = [ctypes.c_int, dp, dp, dp, dp, dp, ctypes.c_double, ctypes.c_double,
+                                    ip, ip, dp, dp, dp, ctypes.c_int, ctypes.c_int]
+        L.orc_pme_spread.argtypes = [ctypes.c_int, dp, dp, dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp]
+        L.orc_pme_gather.argtypes = [ctypes.c_int, dp, dp, dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp, dp]
+        L.orc_min_image.argtypes = [dp, dp, dp]
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+
+
+def min_image(box, d):
+    """Minimum-image of difference vectors d (...,3) in a triclinic box (exhaustive search)."""
+    d = np.asarray(d, dtype=np.float64)
+    flat = d.reshape(-1, 3)
+    s = np.rint(flat[:, 2] / box[2, 2]); flat = flat - s[:, None] * box[2]
+    s = np.rint(flat[:, 1] / box[1, 1]); flat = flat - s[:, None] * box[1]
+    s = np.rint(flat[:, 0] / box[0, 0]); flat = flat - s[:, None] * box[0]
+    best = flat.copy()
+    br2 = (best * best).sum(1)
+    for k in (-1, 0, 1):
+        for j in (-2, -1, 0, 1, 2):
+            for i in (-2, -1, 0, 1, 2):
+                c = flat + i * box[0] + j * box[1] + k * box[2]
+                r2 = (c * c).sum(1)
+                m = r2 < br2
+                best[m] = c[m]; br2[m] = r2[m]
+    return best.reshape(d.shape)
+
+
+def nonbonded(x, q, sigma, eps, box, rc, beta, excl_start, excl_list, flags=3, nthreads=4):
+    """LJ + Ewald real space (+ exclusion correction and self term).
+    Switched on by `coulombtype = PME`, `rcoulomb`, `rvdw`
+    (/root/reference/mdp/production.mdp:24-27). Returns dict(f, e_lj, e_coul_sr, e_excl, vir, npairs)."""
+    n = len(x)
+    xa, xp = _d(x); qa, qp = _d(q); sa, sp = _d(sigma); ea, ep = _d(eps); ba, bp = _d(box)
+    esa, esp = _i(excl_start); ela, elp = _i(excl_list if len(excl_list) else np.zeros(1, np.int32))
+    f = np.zeros((n, 3)); ener = np.zeros(3); vir = np.zeros(9)
+    npairs = lib().orc_nonbonded(n, xp, qp, sp, ep, bp, float(rc), float(beta), esp, elp,
+                                 f.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                 ener.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                 vir.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), int(flags), int(nthreads))
+    return dict(f=f, e_lj=ener[0], e_coul_sr=ener[1], e_excl=ener[2], vir=vir.reshape(3, 3), npairs=int(npairs))
+
+
+# ------------------------------------------------------------------ reciprocal space
+def ewald_recip_direct(x, q, box, beta, tol=1e-12):
+    """Exact Ewald reciprocal sum (no mesh): E = 1/(2 pi V) sum_{m!=0} exp(-pi^2 m^2/beta^2)/m^2 |S(m)|^2."""
+    x = np.asarray(x, float); q = np.asarray(q, float)
+    V = abs(np.linalg.det(box))
+    recip = np.linalg.inv(box)            # s = x @ recip ; mvec = recip @ mint
+    mmax2 = -np.log(tol) * beta ** 2 / np.pi ** 2
+    lim = [int(np.ceil(np.sqrt(mmax2) * np.linalg.norm(box[d]))) + 1 for d in range(3)]
+    g = np.stack(np.meshgrid(*[np.arange(-l, l + 1) for l in lim], indexing="ij"), -1).reshape(-1, 3)
+    g = g[(g != 0).any(1)]
+    mv = g @ recip.T
+    m2 = (mv * mv).sum(1)
+    keep = m2 <= mmax2
+    mv, m2 = mv[keep], m2[keep]
+    E = 0.0; F = np.zeros_like(x); vir = np.zeros((3, 3))
+    pref = ONE_4PI_EPS0 / (2 * np.pi * V)
+    for s in range(0, len(mv), 2048):
+        mvs, m2s = mv[s:s + 2048], m2[s:s + 2048]
+        ph = 2 * np.pi * (x @ mvs.T)                    # (N, M)
+        c, sn = np.cos(ph), np.sin(ph)
+        Sre = q @ c; Sim = q @ sn
+        a = np.exp(-np.pi ** 2 * m2s / beta ** 2) / m2s
+        em = pref * a * (Sre ** 2 + Sim ** 2)
+        E += em.sum()
+        # F_j = -dE/dx_j = pref * a * 2 * q_j * 2pi m (sin*Sre - cos*Sim)
+        coef = (sn * Sre[None, :] - c * Sim[None, :]) * (2 * pref * a)[None, :] * 2 * np.pi
+        F += q[:, None] * (coef @ mvs)
+        fac = 2 * (1 + np.pi ** 2 * m2s / beta ** 2) / m2s
+        vir += -0.5 * (em.sum() * np.eye(3) - np.einsum("m,ma,mb->ab", em * fac, mvs, mvs))
+    return E, F, vir
+
+
+def _bspline_moduli(K, order=4):
+    # M_n at integer arguments 1..n-1
+    def Mn(u, n):
+        if n == 2:
+            return np.where((u >= 0) & (u <= 2), 1 - np.abs(u - 1), 0.0)
+        return (u * Mn(u, n - 1) + (n - u) * Mn(u - 1, n - 1)) / (n - 1)
+    k = np.arange(order - 1)
+    w = Mn(k + 1.0, order)
+    m = np.arange(K)
+    z = (w[None, :] * np.exp(2j * np.pi * m[:, None] * k[None, :] / K)).sum(1)
+    mod = np.abs(z) ** 2
+    # guard the interpolation zero at m = K/2 for odd orders (not hit for order 4)
+    mod[mod < 1e-10] = 1e-10
+    return mod
+
+
+def pme_recip(x, q, box, beta, grid, order=4):
+    """Smooth PME (Essmann 1995) in float64, order 4, grid (nx,ny,nz): the restatement of what
+    `pme_order = 4`, `fourierspacing = 0.16` switch on (/root/reference/mdp/production.mdp:28-29)."""
+    assert order == 4
+    x = np.asarray(x, float); q = np.asarray(q, float)
+    n = len(x)
+    nx, ny, nz = grid
+    V = abs(np.linalg.det(box))
+    recip = np.linalg.inv(box)
+    xa, xp = _d(x); qa, qp = _d(q); ra, rp = _d(recip)
+    Q = np.zeros((nx, ny, nz))
+    lib().orc_pme_spread(n, xp, qp, rp, nx, ny, nz, Q.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    Fq = np.fft.fftn(Q)
+    mi = [np.fft.fftfreq(k, 1.0 / k) for k in (nx, ny, nz)]
+    M = np.stack(np.meshgrid(*mi, indexing="ij"), -1)           # integer m'
+    mv = M @ recip.T
+    m2 = (mv * mv).sum(-1)
+    m2[0, 0, 0] = 1.0
+    B = 1.0 / (_bspline_moduli(nx)[:, None, None] * _bspline_moduli(ny)[None, :, None] * _bspline_moduli(nz)[None, None, :])
+    G = ONE_4PI_EPS0 / (np.pi * V) * np.exp(-np.pi ** 2 * m2 / beta ** 2) / m2 * B
+    G[0, 0, 0] = 0.0
+    em = 0.5 * G * np.abs(Fq) ** 2
+    E = em.sum()
+    fac = 2 * (1 + np.pi ** 2 * m2 / beta ** 2) / m2
+    vir = -0.5 * (E * np.eye(3) - np.einsum("xyz,xyza,xyzb->ab", em * fac, mv, mv))
+    phi = np.real(np.fft.ifftn(G * Fq)) * (nx * ny * nz)
+    phi = np.ascontiguousarray(phi)
+    F = np.zeros((n, 3))
+    lib().orc_pme_gather(n, xp, qp, rp, nx, ny, nz, phi.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                         F.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    return E, F, vir
+
+
+# ------------------------------------------------------------------ bonded
+def bonds(x, idx, b0, kb):
+    """Harmonic bonds V = 1/2 kb (r-b0)^2 (function type 1 of the AMBER .top dialect the
+    pipeline builds, /root/reference/scripts/create_complex_topology.py:65-122)."""
+    f = np.zeros_like(x)
+    if len(idx) == 0:
+        return 0.0, f, np.zeros((3, 3))
+    d = x[idx[:, 0]] - x[idx[:, 1]]
+    r = np.linalg.norm(d, axis=1)
+    e = 0.5 * kb * (r - b0) ** 2
+    fs = (-kb * (r - b0) / r)[:, None] * d
+    np.add.at(f, idx[:, 0], fs); np.add.at(f, idx[:, 1], -fs)
+    vir = -0.5 * np.einsum("na,nb->ab", d, fs)
+    return e.sum(), f, vir
+
+
+def angles(x, idx, th0_deg, k):
+    """Harmonic angles V = 1/2 k (theta-theta0)^2."""
+    f = np.zeros_like(x)
+    if len(idx) == 0:
+        return 0.0, f, np.zeros((3, 3))
+    rij = x[idx[:, 0]] - x[idx[:, 1]]
+    rkj = x[idx[:, 2]] - x[idx[:, 1]]
+    nij = np.linalg.norm(rij, axis=1); nkj = np.linalg.norm(rkj, axis=1)
+    c = np.clip((rij * rkj).sum(1) / (nij * nkj), -1.0, 1.0)
+    th = np.arccos(c)
+    dth = th - np.deg2rad(th0_deg)
+    e = 0.5 * k * dth ** 2
+    dvdth = k * dth
+    st = np.sqrt(np.maximum(1 - c * c, 1e-30))
+    # dtheta/dri = -(1/sin) * d cos/dri
+    dci = (rkj / (nij * nkj)[:, None] - (c / nij ** 2)[:, None] * rij)
+    dck = (rij / (nij * nkj)[:, None] - (c / nkj ** 2)[:, None] * rkj)
+    fi = (dvdth / st)[:, None] * dci
+    fk = (dvdth / st)[:, None] * dck
+    fj = -fi - fk
+    np.add.at(f, idx[:, 0], fi); np.add.at(f, idx[:, 1], fj); np.add.at(f, idx[:, 2], fk)
+    vir = -0.5 * (np.einsum("na,nb->ab", rij, fi) + np.einsum("na,nb->ab", rkj, fk))
+    return e.sum(), f, vir
+
+
+def dihedral_angle(x, idx):
+    rij = x[idx[:, 0]] - x[idx[:, 1]]
+    rkj = x[idx[:, 2]] - x[idx[:, 1]]
+    rkl = x[idx[:, 2]] - x[idx[:, 3]]
+    m = np.cross(rij, rkj); n = np.cross(rkj, rkl)
+    phi = np.arctan2(np.linalg.norm(rkj, axis=1) * (rij * n).sum(1), (m * n).sum(1))
+    return phi, rij, rkj, rkl, m, n
+
+
+def dihedrals(x, idx, phi0_deg, k, mult):
+    """Periodic dihedrals V = k (1 + cos(n phi - phi0)) (function types 1/4/9)."""
+    f = np.zeros_like(x)
+    if len(idx) == 0:
+        return 0.0, f, np.zeros((3, 3))
+    phi, rij, rkj, rkl, m, n = dihedral_angle(x, idx)
+    arg = mult * phi - np.deg2rad(phi0_deg)
+    e = k * (1 + np.cos(arg))
+    ddphi = -k * mult * np.sin(arg)                  # dV/dphi
+    nrkj2 = (rkj * rkj).sum(1); nrkj = np.sqrt(nrkj2)
+    iprm = (m * m).sum(1); iprn = (n * n).sum(1)
+    fi = (-ddphi * nrkj / iprm)[:, None] * m
+    fl = (ddphi * nrkj / iprn)[:, None] * n
+    p = (rij * rkj).sum(1) / nrkj2
+    qq = (rkl * rkj).sum(1) / nrkj2
+    sv = p[:, None] * fi - qq[:, None] * fl
+    fj = fi - sv
+    fk = fl + sv
+    np.add.at(f, idx[:, 0], fi); np.add.at(f, idx[:, 1], -fj); np.add.at(f, idx[:, 2], -fk); np.add.at(f, idx[:, 3], fl)
+    xs = [x[idx[:, a]] for a in range(4)]
+    vir = -0.5 * (np.einsum("na,nb->ab", xs[0], fi) - np.einsum("na,nb->ab", xs[1], fj)
+                  - np.einsum("na,nb->ab", xs[2], fk) + np.einsum("na,nb->ab", xs[3], fl))
+    return e.sum(), f, vir
+
+
+def pairs14(x, idx, c6, c12, qq):
+    """1-4 interactions: V = c12/r^12 - c6/r^6 + qq/(4 pi eps0 r); fudge factors are already
+    folded into c6/c12/qq (AMBER defaults 0.5 / 0.8333)."""
+    f = np.zeros_like(x)
+    if len(idx) == 0:
+        return 0.0, 0.0, f, np.zeros((3, 3))
+    d = x[idx[:, 0]] - x[idx[:, 1]]
+    r2 = (d * d).sum(1); rinv2 = 1 / r2; rinv6 = rinv2 ** 3
+    elj = c12 * rinv6 ** 2 - c6 * rinv6
+    ec = ONE_4PI_EPS0 * qq * np.sqrt(rinv2)
+    fs = ((12 * c12 * rinv6 ** 2 - 6 * c6 * rinv6 + ec) * rinv2)[:, None] * d
+    np.add.at(f, idx[:, 0], fs); np.add.at(f, idx[:, 1], -fs)
+    vir = -0.5 * np.einsum("na,nb->ab", d, fs)
+    return elj.sum(), ec.sum(), f, vir
+
+
+def posres(x, box, idx, ref, k):
+    """Position restraints V = 1/2 sum_d k_d (x_d - ref_d)^2 with minimum image
+    (`define = -DPOSRES`, /root/reference/mdp/nvt_complex.mdp:2)."""
+    f = np.zeros_like(x)
+    if len(idx) == 0:
+        return 0.0, f, np.zeros((3, 3))
+    d = min_image(box, x[idx] - ref)
+    e = 0.5 * (k * d * d).sum()
+    fs = -k * d
+    np.add.at(f, idx, fs)
+    vir = -0.5 * np.einsum("na,nb->ab", d, fs)
+    return e, f, vir
+
+
+def dispersion_correction(sigma, eps, box, rc, excl_start=None):
+    """Long-range dispersion correction for energy and pressure (`DispCorr = EnerPres`,
+    /root/reference/mdp/production.mdp:44) with <C6> averaged over all atom pairs
+    (Lorentz-Berthelot C6_ij = 4 eps_ij sigma_ij^6). Returns (E_disp, P_disp[bar]).
+    The energy also carries the constant that the potential-shift modifier removes inside rc."""
+    n = len(sigma)
+    # group by unique (sigma, eps) to form the pair average exactly
+    key = np.stack([sigma, eps], 1)
+    uniq, cnt = np.unique(key, axis=0, return_counts=True)
+    s = 0.5 * (uniq[:, None, 0] + uniq[None, :, 0]); e = np.sqrt(uniq[:, None, 1] * uniq[None, :, 1])
+    c6 = 4 * e * s ** 6
+    npair = 0.5 * n * (n - 1)
+    tot = 0.5 * ((cnt[:, None] * cnt[None, :] * c6).sum() - (cnt * np.diag(c6)).sum())
+    avg = tot / npair
+    V = abs(np.linalg.det(box))
+    e_tail = -(2.0 / 3.0) * np.pi * n * n / V * avg / rc ** 3
+    # inside rc the pair kernel uses V(r) - V(rc); restoring the dispersion part -C6/rc^6 for the
+    # N^2/(2V) * 4/3 pi rc^3 pairs inside the cut-off gives a second, equal term
+    e_disp = 2.0 * e_tail
+    p_disp = -(4.0 / 3.0) * np.pi * n * n / (V * V) * avg / rc ** 3 * PRESFAC
+    return e_disp, p_disp
+
+
+def all_forces(s, rc, beta, grid=None, nthreads=4, pme="mesh"):
+    """Every force term of one MDSystem; returns dict of per-term (E, F) and totals."""
+    out = {}
+    nb = nonbonded(s.x, s.charge, s.sigma, s.eps, s.box, rc, beta, s.excl_start, s.excl_list, 3, nthreads)
+    out["nb"] = nb
+    F = nb["f"].copy()
+    vir = nb["vir"].copy()
+    if pme == "mesh":
+        e, f, v = pme_recip(s.x, s.charge, s.box, beta, grid)
+    else:
+        e, f, v = ewald_recip_direct(s.x, s.charge, s.box, beta)
+    out["recip"] = (e, f); F += f; vir += v
+    e, f, v = bonds(s.x, s.bonds, s.bond_b0, s.bond_kb); out["bonds"] = (e, f); F += f; vir += v
+    e, f, v = angles(s.x, s.angles, s.angle_th0, s.angle_k); out["angles"] = (e, f); F += f; vir += v
+    e, f, v = dihedrals(s.x, s.dihedrals, s.dih_phi0, s.dih_k, s.dih_mult); out["dihedrals"] = (e, f); F += f; vir += v
+    elj, ec, f, v = pairs14(s.x, s.pairs14, s.pair_c6, s.pair_c12, s.pair_qq); out["pairs14"] = (elj, ec, f); F += f; vir += v
+    out["f"] = F; out["vir"] = vir
+    return out
