@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Benchmark contract: python bench.py --gpus N --steps K --warmup W  -> one JSON line on rank 0.
+
+Workload (N=1 and every N as independent replicas, weak scaling): the synthetic pseudo-complex
+(alkane-bundle "protein" + 44-atom ligand + Na+ + TIP3P, rhombic dodecahedron d = 12.5 nm,
+~1.4e5 atoms) run with the settings of /root/reference/mdp/production.mdp (dt 2 fs, rc 1.0 nm,
+PME order 4 / 0.16 nm, h-bond constraints, V-rescale on Protein / Non-Protein, energies every
+10 steps, DispCorr EnerPres) and the C-rescale barostat that BASELINE.json's config names.
+A "step" is one MD step. Metric: ns/day = dt * steps * 86400 / wall / 1000 summed over replicas.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def build_system(args):
+    import mdx  # noqa: F401
+    from mdx import synth
+    if args.system == "complex":
+        s = synth.pseudo_complex(d=args.box)
+    else:
+        s = synth.water_box(d=args.box)
+    return s
+
+
+def engine_for(s, args, phase, seed, device):
+    from mdx import engine as eng
+    tc = ["Protein", "Non-Protein"] if args.system == "complex" else ["System"]
+    rc = 1.2 if args.workload == "smd" else 1.0
+    common = dict(rc=rc, pme=True, fourierspacing=0.16, device=device, tc_groups=tc, ref_t=[300.0] * len(tc),
+                  seed=seed, lincs_order=4, lincs_iter=1)
+    if phase == "relax":      # un-timed preparation from the lattice start
+        return eng.Engine(s, dt=0.0005, nstlist=10, nstcalcenergy=0, tau_t=[0.02] * len(tc), nsttcouple=2, **common)
+    if phase == "equil":
+        return eng.Engine(s, dt=0.002, nstlist=10, nstcalcenergy=0, tau_t=[0.1] * len(tc), nsttcouple=10, **common)
+    if args.workload == "smd":  # pull_short.mdp: dt 1 fs, rc 1.2, NVT, 4 T-groups, lincs 6/2, COM pull
+        common.update(tc_groups=["Protein", "MOL", "SOL", "NA"], ref_t=[300.0] * 4, lincs_order=6, lincs_iter=2)
+        e = eng.Engine(s, dt=0.001, nstlist=args.nstlist, nstcalcenergy=100, tau_t=[0.1] * 4, nsttcouple=10, **common)
+        e.set_pull(s.groups["ActiveSite"], s.groups["MOL"], type="constant-force", k=500.0, nstout=50)
+        return e
+    pc = {"c-rescale": 1, "parrinello-rahman": 2, "no": 0}[args.pcoupl]
+    return eng.Engine(s, dt=0.002, nstlist=args.nstlist, nstcalcenergy=10, tau_t=[0.1] * len(tc), nsttcouple=10,
+                      pcoupl=pc, tau_p=2.0, ref_p=1.0, compressibility=4.5e-5, nstpcouple=10, dispcorr=2, **common)
+
+
+def carry(s, e):
+    import copy
+    x, v, box = e.get_state()
+    t = copy.copy(s)
+    t.x = x.astype(np.float64); t.v = v.astype(np.float64); t.box = box.astype(np.float64)
+    return t
+
+
+def cpu_baseline(s, rc, grid, dt, nsteps, threads):
+    """Oracle (float64 C + numpy) timed on the host: a reported baseline, never the product."""
+    from oracle import mdref as R
+    import importlib
+    U = importlib.import_module("molecular-dynamics_amd.units")
+    import copy
+    st = copy.copy(s)
+    v = s.v.copy()
+    beta = U.ewald_beta(rc)
+    t0 = time.time()
+    for _ in range(nsteps):
+        x, v, _ = R.md_step(st, v, rc, beta, grid, dt, nthreads=threads)
+        st.x = x
+    wall = time.time() - t0
+    return dt * nsteps * 86400.0 / wall / 1000.0, wall
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5000)
+    ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--system", default="complex", choices=["complex", "water"])
+    ap.add_argument("--box", type=float, default=12.5)
+    ap.add_argument("--workload", default="production", choices=["production", "smd"])
+    ap.add_argument("--pcoupl", default="c-rescale", choices=["c-rescale", "parrinello-rahman", "no"])
+    ap.add_argument("--nstlist", type=int, default=10)
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prep-steps", type=int, default=2000)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import mdx  # noqa: F401
+    from mdx import engine as eng, ensemble
+    s = build_system(args)
+    seed = ensemble.replica_seed(20250829, rank)
+    # ---- preparation (not timed): relax the lattice start, then equilibrate at the production time step
+    e = engine_for(s, args, "relax", seed, local); e.step(args.prep_steps); s1 = carry(s, e); e.close()
+    e = engine_for(s1, args, "equil", seed, local); e.step(args.prep_steps); s2 = carry(s1, e); e.close()
+    e = engine_for(s2, args, "run", seed, local)
+    dt = e.dt
+    # ---- warmup
+    e.step(args.warmup); e.synchronize()
+    e.pop_energy_frames()
+    e.enable_kernel_timing(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    e.step(args.steps)
+    e.synchronize(); torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    nb_ms, nb_launches = e.kernel_timing()
+    e.enable_kernel_timing(False)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed_max = float(tmax.item())
+    frames = e.pop_energy_frames()
+    stats = e.list_stats()
+    smd = None
+    if args.workload == "smd":
+        rec = e.pop_pull_records()
+        allw = ensemble.gather_work(rec[:, 3])
+        dF = ensemble.jarzynski_free_energy(allw, 300.0)
+        smd = dict(samples=int(len(rec)), replicas=int(allw.shape[0]), final_distance=float(rec[-1, 1]) if len(rec) else None,
+                   jarzynski_dF_final=float(dF[-1]) if len(dF) else None)
+    elif world > 1:
+        # replicas only: one tiny RCCL all-gather of the final potential energies (no data-path collective)
+        allw = ensemble.gather_work(np.array([frames[-1, 2 + eng.E["POT"]]]))
+    ns_day = dt * args.steps * 86400.0 / elapsed_max / 1000.0 * world
+    out = None
+    if rank == 0:
+        n_rc, n_lj = stats["pairs_within_rc"], stats["pairs_with_lj"]
+        flops = 66.0 * n_lj + 54.0 * (n_rc - n_lj)
+        nb_avg_s = nb_ms / max(nb_launches, 1) * 1e-3
+        achieved = flops / nb_avg_s / 1e12 if nb_avg_s > 0 else 0.0
+        peak = 157.3
+        out = {
+            "metric": "ns/day", "value": round(ns_day, 3), "unit": "ns/day", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 5), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("pseudo-complex S2 (%d atoms, dodecahedron d=%.1f nm), production.mdp settings, "
+                                    "%s barostat, energies every 10 steps" % (s.natoms, args.box, args.pcoupl))
+                       if args.workload == "production" else
+                       ("pseudo-complex S2 (%d atoms), pull_short.mdp settings, constant-force COM pull, one replica per GPU" % s.natoms),
+                       "natoms": s.natoms, "dt_ps": dt, "rc_nm": e.rc, "rlist_nm": round(e.rlist, 4), "nstlist": args.nstlist,
+                       "pme_grid": list(e.grid), "parallelism": "replicas x%d" % world},
+            "pair_interactions_per_s": round(n_rc / nb_avg_s, 1) if nb_avg_s > 0 else None,
+            "pair_interactions_per_s_end_to_end": round(n_rc * args.steps / elapsed_max * world, 1),
+            "roofline": {"bound": "valu_f32", "kernel": "k_nonbonded", "achieved": round(achieved, 3), "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                         "peak_unpacked": 78.6, "frac_unpacked": round(achieved / 78.6, 4),
+                         "flops_per_launch": flops, "pairs_within_rc": n_rc, "pairs_with_lj": n_lj,
+                         "avg_launch_ms": round(nb_avg_s * 1e3, 5), "launches": nb_launches,
+                         "evaluated_pair_lanes": stats["cluster_pairs"] * 64},
+            "final": {"T": float(frames[-1, 2 + eng.E["TEMP"]]) if len(frames) else None,
+                      "P_bar": float(frames[-1, 2 + eng.E["PRES"]]) if len(frames) else None,
+                      "Epot": float(frames[-1, 2 + eng.E["POT"]]) if len(frames) else None,
+                      "volume": float(frames[-1, 2 + eng.E["VOLUME"]]) if len(frames) else None},
+        }
+        if smd:
+            out["smd"] = smd
+        if not args.no_cpu_baseline and world == 1:
+            s3 = carry(s2, e)
+            threads = 4   # the pipeline runs gmx mdrun with -ntomp 4 (/root/reference/Snakefile:232-233)
+            v, wall = cpu_baseline(s3, e.rc, e.grid, dt, args.cpu_steps, threads)
+            out["cpu_baseline"] = {"value": round(v, 5), "unit": "ns/day", "cores": threads, "kind": "port",
+                                   "sample": "%d leap-frog steps of the same %d-atom system with the float64 oracle "
+                                             "(C cell-list nonbonded on %d OpenMP threads, numpy PME/bonded/SHAKE), %.1f s; "
+                                             "own CPU restatement, not GROMACS" % (args.cpu_steps, s.natoms, threads, wall)}
+        print(json.dumps(out), flush=True)
+    e.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

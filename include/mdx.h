@@ -152,9 +152,11 @@ int mdx_get_virial(mdx_system *sys, double *vir9, double *pres9);
  * on the handle's stream and returns; any getter synchronises. */
 int mdx_step(mdx_system *sys, long long nsteps);
 int mdx_synchronize(mdx_system *sys);
-/* Pair-list statistics of the last search: [0] super-clusters, [1] j-cluster entries,
- * [2] work units, [3] exclusion masks, [4] cluster pairs (set bits of the i-masks). */
-int mdx_get_list_stats(mdx_system *sys, long long *stats5);
+/* Pair-list statistics (8 values): of the last search [0] super-clusters, [1] j-cluster
+ * entries, [2] work units, [3] exclusion masks, [4] cluster pairs (set bits of the i-masks);
+ * of the last energy step [5] non-excluded atom pairs with r < rc (each once), [6] those of
+ * them with a Lennard-Jones term; [7] reserved. */
+int mdx_get_list_stats(mdx_system *sys, long long *stats8);
 /* Energy frames recorded every nstcalcenergy steps since the last call: each frame is
  * (step, time, MDX_E_N terms). Returns the number of frames copied (<= max_frames). */
 long long mdx_pop_energy_frames(mdx_system *sys, double *out, long long max_frames);

@@ -576,6 +576,7 @@ extern "C" int mdx_get_list_stats(mdx_system *s, long long *st)
     long long bits = 0;
     for (const NbEntry &x : e) bits += __builtin_popcount(x.mask & 0xFFu);
     st[4] = bits;
+    st[5] = (long long)s->h->npairs_rc; st[6] = (long long)s->h->npairs_lj; st[7] = 0;
     return MDX_OK;
 }
 

@@ -46,6 +46,8 @@ struct DevState {
     int pull_have_init;
     int pad1;
     long long step;
+    // pair counters of the last energy step: non-excluded pairs with r < rc, and those with LJ
+    unsigned long long npairs_rc, npairs_lj;
 };
 
 struct NbEntry { int cj; unsigned int mask; };        // mask: bits 0-7 i-cluster mask, bits 8.. exclusion slot

@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void k_nonbonded(NbArgs A)
     const int nwork = A.d->nwork;
     const int nwaves = gridDim.x * 4;
     float elj = 0.0f, ecoul = 0.0f;
+    unsigned int npair = 0, nlj = 0;
     float vxx = 0.0f, vxy = 0.0f, vxz = 0.0f, vyy = 0.0f, vyz = 0.0f, vzz = 0.0f;
     const float rc2 = A.rc2, beta = A.beta;
     const float nb2l2e = -beta * beta * 1.4426950408889634f; // exp(-b^2 r^2) = exp2(nb2l2e * r2)
@@ -108,9 +109,12 @@ __global__ __launch_bounds__(256) void k_nonbonded(NbArgs A)
                 fjx -= fx; fjy -= fy; fjz -= fz;
                 if (ENERGY) {
                     if (within) {
+                        npair++;
+                        if (e4 != 0.0f) nlj++;
                         const float c2 = sg * sg * (1.0f / rc2);
                         const float c6 = c2 * c2 * c2;
-                        elj += e4 * (fmaf(s6, s6, -s6) - fmaf(c6, c6, -c6));
+                        // t6 (s6 - 1) stays finite when e4 = 0 and s6 is huge (filler atoms)
+                        elj += t6 * (s6 - 1.0f) - e4 * c6 * (c6 - 1.0f);
                         ecoul += qq * (erfc_br * rinv - A.c_rf_shift);
                     }
                     vxx = fmaf(dx, fx, vxx); vxy = fmaf(dx, fy, vxy); vxz = fmaf(dx, fz, vxz);
@@ -142,7 +146,12 @@ __global__ __launch_bounds__(256) void k_nonbonded(NbArgs A)
         elj = wave_sum(elj); ecoul = wave_sum(ecoul);
         vxx = wave_sum(vxx); vxy = wave_sum(vxy); vxz = wave_sum(vxz);
         vyy = wave_sum(vyy); vyz = wave_sum(vyz); vzz = wave_sum(vzz);
+        unsigned long long np64 = npair, nl64 = nlj;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { np64 += __shfl_xor(np64, o, 64); nl64 += __shfl_xor(nl64, o, 64); }
         if (lane == 0) {
+            atomicAdd(&A.dw->npairs_rc, np64);
+            atomicAdd(&A.dw->npairs_lj, nl64);
             atomicAdd(&A.dw->ener[MDX_E_LJ], (double)elj);
             atomicAdd(&A.dw->ener[MDX_E_COUL_SR], (double)ecoul);
             double *v = A.dw->vir;

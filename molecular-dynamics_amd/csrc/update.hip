@@ -443,6 +443,7 @@ __global__ void k_clear(DevState *dw, int energies, int ekin_new, int ekin_old)
     if (energies) {
         if (t < MDX_E_N) dw->ener[t] = 0.0;
         if (t < 9) { dw->vir[t] = 0.0; dw->ekin_tensor[t] = 0.0; }
+        if (t == 0) { dw->npairs_rc = 0; dw->npairs_lj = 0; }
     }
     if (t < MDX_MAX_TC) {
         if (ekin_new) dw->ekinh[t] = 0.0;

@@ -308,6 +308,9 @@ def pseudo_complex(d: float = 12.5, protein_radius: float = 2.1, density: float 
     centres, _ = water_sites(box, density)
     from scipy.spatial import cKDTree
     xs = np.concatenate([xp, xl])
+    # include the periodic images of the solute so that waters are also carved across the cell faces
+    imgs = [i * box[0] + j * box[1] + k * box[2] for i in (-1, 0, 1) for j in (-1, 0, 1) for k in (-1, 0, 1)]
+    xs = np.concatenate([xs + s_ for s_ in imgs])
     tree = cKDTree(xs)
     dmin, _ = tree.query(centres, k=1)
     keep = dmin > 0.33

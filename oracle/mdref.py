@@ -313,3 +313,134 @@ def all_forces(s, rc, beta, grid=None, nthreads=4, pme="mesh"):
     elj, ec, f, v = pairs14(s.x, s.pairs14, s.pair_c6, s.pair_c12, s.pair_qq); out["pairs14"] = (elj, ec, f); F += f; vir += v
     out["f"] = F; out["vir"] = vir
     return out
+
+
+# ------------------------------------------------------------------ dynamics
+def shake(x_old, x_new, cons, lens, invmass, tol=1e-13, maxit=500):
+    """Classic SHAKE (Ryckaert 1977) to machine precision: the exact solution that both
+    SETTLE (`[ settles ]` in tip3p.itp) and LINCS (`constraint_algorithm = lincs`,
+    /root/reference/mdp/production.mdp:16) approximate. Displacements act along the OLD bond
+    vectors. Returns the constrained positions."""
+    x = x_new.copy()
+    if len(cons) == 0:
+        return x
+    a, b = cons[:, 0], cons[:, 1]
+    r0 = x_old[a] - x_old[b]
+    l2 = lens ** 2
+    for _ in range(maxit):
+        d = x[a] - x[b]
+        diff = (d * d).sum(1) - l2
+        if np.abs(diff / l2).max() < tol:
+            break
+        # Gauss-Seidel over constraints, vectorised per "colour" is overkill here: Jacobi with
+        # under-relaxation converges for the small coupled sets in scope (water triangles, XH3)
+        g = diff / (2.0 * (invmass[a] + invmass[b]) * (d * r0).sum(1))
+        corr = g[:, None] * r0
+        dx = np.zeros_like(x)
+        np.add.at(dx, a, -invmass[a][:, None] * corr)
+        np.add.at(dx, b, invmass[b][:, None] * corr)
+        x += 0.6 * dx
+    return x
+
+
+def settle_water(x_old, x_new, settles, m_o, m_h, doh, dhh):
+    """Rigid water constraint via converged SHAKE on the three distances."""
+    if len(settles) == 0:
+        return x_new.copy()
+    o, h1, h2 = settles[:, 0], settles[:, 1], settles[:, 2]
+    cons = np.concatenate([np.stack([o, h1], 1), np.stack([o, h2], 1), np.stack([h1, h2], 1)])
+    lens = np.concatenate([np.full(len(o), doh), np.full(len(o), doh), np.full(len(o), dhh)])
+    invmass = np.zeros(len(x_new))
+    invmass[o] = 1.0 / m_o; invmass[h1] = 1.0 / m_h; invmass[h2] = 1.0 / m_h
+    return shake(x_old, x_new, cons, lens, invmass)
+
+
+def lincs(x_old, x_new, cons, lens, invmass, order=4, niter=1):
+    """LINCS (Hess et al. 1997) with expansion order and correction iterations as the .mdp sets
+    them (`lincs_order`, `lincs_iter`, /root/reference/mdp/production.mdp:18-19;
+    pull_short.mdp:14-15)."""
+    x = x_new.copy()
+    K = len(cons)
+    if K == 0:
+        return x
+    a, b = cons[:, 0], cons[:, 1]
+    d0 = x_old[a] - x_old[b]
+    B = d0 / np.linalg.norm(d0, axis=1)[:, None]
+    S = 1.0 / np.sqrt(invmass[a] + invmass[b])
+    A = np.zeros((K, K))
+    # coupling only between constraints sharing an atom
+    from collections import defaultdict
+    by_atom = defaultdict(list)
+    for k in range(K):
+        by_atom[int(a[k])].append(k); by_atom[int(b[k])].append(k)
+    for atom, ks in by_atom.items():
+        for k in ks:
+            for m in ks:
+                if k == m:
+                    continue
+                same = (a[k] == atom) == (a[m] == atom)
+                A[k, m] = (-1.0 if same else 1.0) * invmass[atom] * S[k] * S[m] * (B[k] * B[m]).sum()
+
+    def solve(rhs):
+        sol = rhs.copy()
+        for _ in range(order):
+            rhs = A @ rhs
+            sol += rhs
+        return sol
+
+    def apply(lam):
+        np.add.at(x, a, -(invmass[a] * lam)[:, None] * B)
+        np.add.at(x, b, (invmass[b] * lam)[:, None] * B)
+
+    d = x[a] - x[b]
+    apply(S * solve(S * ((B * d).sum(1) - lens)))
+    for _ in range(niter):
+        d = x[a] - x[b]
+        p = np.sqrt(np.maximum(2 * lens ** 2 - (d * d).sum(1), 0.0))
+        apply(S * solve(S * (lens - p)))
+    return x
+
+
+def vrescale_new_ekin(ek, ekref, ndf, dt_tc, tau_t, r1, chi2_rest):
+    """V-rescale target kinetic energy (Bussi, Donadio, Parrinello 2007) for given random
+    draws: r1 ~ N(0,1), chi2_rest ~ chi^2(ndf-1) (`tcoupl = V-rescale`,
+    /root/reference/mdp/production.mdp:31)."""
+    c = np.exp(-dt_tc / tau_t)
+    return ek + (1 - c) * (ekref * (chi2_rest + r1 * r1) / ndf - ek) + 2 * r1 * np.sqrt(c * (1 - c) * ek * ekref / ndf)
+
+
+def crescale_mu(P, P0, compress, tau_p, dt_pc, vol, kT, gauss):
+    """Isotropic C-rescale scaling factor (Bernetti & Bussi 2020)."""
+    deps = -(compress / tau_p) * (P0 - P) * dt_pc + np.sqrt(2 * kT * compress * PRESFAC * dt_pc / (vol * tau_p)) * gauss
+    return np.exp(deps / 3.0)
+
+
+def pull_distance(x, box, mass, g1, g2, pbc1=None, pbc2=None):
+    """COM distance between two groups with a per-group PBC reference atom (number-wise
+    middle atom by default), as `pull_coord1_geometry = distance` defines it
+    (/root/reference/mdp/pull_short.mdp:42). Returns (r, unit vector from COM1 to COM2, COM1, COM2)."""
+    coms = []
+    for g, p in ((g1, pbc1), (g2, pbc2)):
+        p = (len(g) - 1) // 2 if p is None or p < 0 else p
+        xr = x[g[p]]
+        d = min_image(box, x[g] - xr)
+        coms.append(xr + (mass[g][:, None] * d).sum(0) / mass[g].sum())
+    dr = min_image(box, (coms[1] - coms[0])[None, :])[0]
+    r = np.linalg.norm(dr)
+    return r, dr / r, coms[0], coms[1]
+
+
+def md_step(s, v, rc, beta, grid, dt, nthreads=4):
+    """One plain leap-frog step with all force terms, SETTLE and LINCS (no coupling): the
+    per-step work of `gmx mdrun` for `integrator = md`, restated for the CPU baseline timing."""
+    out = all_forces(s, rc, beta, grid, nthreads)
+    invm = 1.0 / s.mass
+    v_new = v + out["f"] * invm[:, None] * dt
+    x_new = s.x + v_new * dt
+    xc = x_new
+    if len(s.settles):
+        xc = settle_water(s.x, xc, s.settles, s.mass[s.settles[0, 0]], s.mass[s.settles[0, 1]], s.settle_doh, s.settle_dhh)
+    if len(s.constraints):
+        xc = lincs(s.x, xc, s.constraints, s.constraint_len, invm, 4, 1)
+    v_new = v_new + (xc - x_new) / dt
+    return xc, v_new, out

@@ -1,0 +1,86 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/mdx.h declares,
+fails loudly without a GPU, and the synthetic generators produce consistent topologies."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import mdx  # noqa: F401
+from mdx import synth, engine as eng
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "mdx.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mdx_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(eng.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"libmdx.so does not export {n}"
+    assert sorted(eng.SYMBOLS) == names
+
+
+def test_create_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = eng.load_library()
+    h = lib.mdx_create(0, 100)
+    assert not h
+    assert b"no HIP device" in lib.mdx_last_error(None)
+    with pytest.raises(eng.MdxError):
+        eng.Engine(synth.water_box(d=3.2))
+
+
+def test_water_box_geometry_and_neutrality():
+    s = synth.water_box(d=3.4)
+    s.validate()
+    assert s.natoms % 3 == 0 and abs(s.charge.sum()) < 1e-9
+    d = np.linalg.norm(s.x[0::3] - s.x[1::3], axis=1)
+    assert np.allclose(d, 0.09572, atol=1e-12)
+    dens = (s.natoms / 3) / abs(np.linalg.det(s.box))
+    assert 30 < dens < 36
+    # exclusions are symmetric
+    for i in (0, 1, 2, 100):
+        for j in s.excl_list[s.excl_start[i]:s.excl_start[i + 1]]:
+            assert i in s.excl_list[s.excl_start[j]:s.excl_start[j + 1]]
+
+
+def test_pseudo_complex_topology(small_complex):
+    s = small_complex
+    s.validate()
+    assert abs(s.charge.sum()) < 1e-9
+    assert len(s.groups["MOL"]) == 44
+    assert set(s.groups) >= {"System", "Protein", "Non-Protein", "MOL", "SOL", "NA", "ActiveSite"}
+    assert len(s.groups["Protein"]) + len(s.groups["Non-Protein"]) == s.natoms
+    # every constraint involves a hydrogen; no flexible bond does
+    isH = s.mass < 1.1
+    assert (isH[s.constraints[:, 0]] | isH[s.constraints[:, 1]]).all()
+    assert not (isH[s.bonds[:, 0]] | isH[s.bonds[:, 1]]).any()
+    # no non-excluded LJ overlap, also across the periodic faces
+    from oracle import mdref as R
+    o = R.nonbonded(s.x, s.charge * 0, s.sigma, s.eps, s.box, 1.0, 3.0, s.excl_start, s.excl_list, flags=1)
+    assert o["e_lj"] < 0 and np.abs(o["f"]).max() < 5e3
+
+
+def test_rlist_and_grid_helpers():
+    import importlib
+    U = importlib.import_module("molecular-dynamics_amd.units")
+    assert eng.verlet_rlist(1.0, 10, 0.002) > 1.0
+    assert eng.verlet_rlist(1.0, 40, 0.002) > eng.verlet_rlist(1.0, 10, 0.002)
+    g = U.pme_grid(synth.dodecahedron_box(12.5), 0.16)
+    assert g == (80, 80, 56)
+    for k in g:
+        m = k
+        for p in (2, 3, 5, 7):
+            while m % p == 0:
+                m //= p
+        assert m == 1

@@ -12,6 +12,7 @@ def relrms(a, b):
     return float(np.sqrt(((a - b) ** 2).sum() / (b ** 2).sum()))
 
 def parity(name, s, rc=1.0, **kw):
+    s.x = s.x.astype(np.float32).astype(np.float64)   # both sides see the same float32 inputs
     print(f"== {name}: {s.natoms} atoms", flush=True)
     e = eng.Engine(s, rc=rc, nstcalcenergy=1, **kw)
     beta, grid = e.beta, e.grid
