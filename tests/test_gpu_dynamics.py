@@ -115,7 +115,7 @@ def test_pressure_coupling_relaxes_density(equilibrated_water, kind):
     fr = e.pop_energy_frames(); e.close()
     vol = fr[:, 2 + eng.E["VOLUME"]]; P = fr[:, 2 + eng.E["PRES"]]
     assert np.isfinite(vol).all() and np.isfinite(P).all()
-    dens = (s.natoms / 3) * 18.015 / 6.02214e23 / (vol * 1e-21) / 1000   # g/cm^3... kg/L
+    dens = (s.natoms / 3) * 18.015 / 6.02214e23 / (vol * 1e-21)   # g/cm^3
     # TIP3P at 300 K / 1 bar: ~0.98 g/cm^3; the lattice start is 33.8 molecules/nm^3 = 1.01 g/cm^3
     assert 0.93 < dens[-20:].mean() < 1.05
     assert vol[-1] != vol[0]

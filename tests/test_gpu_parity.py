@@ -121,7 +121,7 @@ def test_pair_list_covers_every_pair_within_cutoff(eng_water, small_water):
     """Energy from the cluster list equals the oracle's exact all-pairs sum, so no pair within
     rc is missing and none is counted twice; rlist buffer does not change the result."""
     s = small_water
-    e2 = eng.Engine(s, rc=1.0, rlist=1.25, nstcalcenergy=1)
+    e2 = eng.Engine(s, rc=1.0, rlist=1.18, nstcalcenergy=1)
     _, en_a = eng_water.compute(eng.F_NONBONDED)
     _, en_b = e2.compute(eng.F_NONBONDED)
     e2.close()
