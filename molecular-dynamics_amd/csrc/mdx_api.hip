@@ -58,7 +58,10 @@ extern "C" mdx_system *mdx_create(int device, int natoms)
     if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return nullptr; }
     mdx_system *s = new mdx_system();
     s->device = device; s->n = natoms;
-    bool ok = hipStreamCreate(&s->stream) == hipSuccess;
+    bool ok = hipStreamCreate(&s->stream) == hipSuccess && hipStreamCreate(&s->st_pme) == hipSuccess &&
+              hipStreamCreate(&s->st_bond) == hipSuccess && hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&s->ev_pme, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&s->ev_bond, hipEventDisableTiming) == hipSuccess;
     const int n = natoms;
     s->ncol_cap = n / 128 + 256;
     s->npad = ((n + 63) / 64 + s->ncol_cap) * 64;
@@ -66,7 +69,7 @@ extern "C" mdx_system *mdx_create(int device, int natoms)
     s->work_cap = s->cj_cap / 8 + 1024;
     s->excl_cap = n + 1024;
     auto A = [&](auto **p, size_t c) { ok = ok && (dev_alloc(s, p, c) == MDX_OK); };
-    A(&s->x, n); A(&s->xp, n); A(&s->v, n); A(&s->f, 3 * (size_t)n); A(&s->lj, n); A(&s->molid, n); A(&s->tcgrp, n);
+    A(&s->x, n); A(&s->xp, n); A(&s->v, n); A(&s->f, 3 * (size_t)n); A(&s->f_pme, 3 * (size_t)n); A(&s->lj, n); A(&s->molid, n); A(&s->tcgrp, n);
     A(&s->xq_s, s->npad); A(&s->lj_s, s->npad); A(&s->f_s, 3 * (size_t)s->npad); A(&s->perm, s->npad); A(&s->perm_src, s->npad);
     A(&s->shift_s, s->npad); A(&s->molid_s, s->npad); A(&s->sorted_of, n);
     A(&s->bb_lo, s->npad / 8); A(&s->bb_hi, s->npad / 8); A(&s->sbb_lo, s->npad / 64); A(&s->sbb_hi, s->npad / 64);
@@ -89,6 +92,7 @@ extern "C" mdx_system *mdx_create(int device, int natoms)
     (void)hipMemset(s->excl_start, 0, sizeof(int) * (n + 1));
     (void)hipMemset(s->tcgrp, 0, sizeof(int) * n);
     (void)hipMemset(s->f, 0, sizeof(float) * 3 * n);
+    (void)hipMemset(s->f_pme, 0, sizeof(float) * 3 * n);
     (void)hipMemset(s->f_s, 0, sizeof(float) * 3 * s->npad);
     (void)hipMemset(s->sorted_of, 0, sizeof(int) * n);
     return s;
@@ -98,9 +102,9 @@ extern "C" void mdx_destroy(mdx_system *s)
 {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    (void)hipDeviceSynchronize();
     mdx_pme_free(s);
-    void *ptrs[] = { s->x, s->xp, s->v, s->f, s->lj, s->molid, s->tcgrp, s->excl_start, s->excl_list, s->excl_pairs, s->xq_s, s->lj_s,
+    void *ptrs[] = { s->x, s->xp, s->v, s->f, s->f_pme, s->lj, s->molid, s->tcgrp, s->excl_start, s->excl_list, s->excl_pairs, s->xq_s, s->lj_s,
                      s->f_s, s->perm, s->perm_src, s->shift_s, s->molid_s, s->sorted_of, s->bb_lo, s->bb_hi, s->sbb_lo, s->sbb_hi,
                      s->col_count, s->col_astart, s->col_scstart, s->col_atoms, s->atom_col, s->atom_slot, s->wrapped, s->cj, s->work,
                      s->exclmask, s->shift_ijk, s->shiftvec, s->bond_ij, s->bond_p, s->angle_ijk, s->angle_p, s->dih_ijkl, s->dih_p,
@@ -111,6 +115,11 @@ extern "C" void mdx_destroy(mdx_system *s)
     if (s->ener_log) (void)hipHostFree(s->ener_log);
     if (s->pull_log) (void)hipHostFree(s->pull_log);
     for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    if (s->ev_pme) (void)hipEventDestroy(s->ev_pme);
+    if (s->ev_bond) (void)hipEventDestroy(s->ev_bond);
+    if (s->st_pme) (void)hipStreamDestroy(s->st_pme);
+    if (s->st_bond) (void)hipStreamDestroy(s->st_bond);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -513,6 +522,24 @@ static int record_energy_frame(mdx_system *s)
 
 static std::vector<long long> &frame_steps(mdx_system *s) { return s->frame_steps; }
 
+// The PME chain and the bonded-type kernels run on their own streams next to the nonbonded
+// kernel: fork after the sorted coordinates are ready, join before the update.
+int mdx_fork(mdx_system *s)
+{
+    MDX_CHECK(s, hipEventRecord(s->ev_fork, s->stream));
+    MDX_CHECK(s, hipStreamWaitEvent(s->st_pme, s->ev_fork, 0));
+    MDX_CHECK(s, hipStreamWaitEvent(s->st_bond, s->ev_fork, 0));
+    return MDX_OK;
+}
+int mdx_join(mdx_system *s)
+{
+    MDX_CHECK(s, hipEventRecord(s->ev_pme, s->st_pme));
+    MDX_CHECK(s, hipEventRecord(s->ev_bond, s->st_bond));
+    MDX_CHECK(s, hipStreamWaitEvent(s->stream, s->ev_pme, 0));
+    MDX_CHECK(s, hipStreamWaitEvent(s->stream, s->ev_bond, 0));
+    return MDX_OK;
+}
+
 extern "C" int mdx_compute_forces(mdx_system *s, unsigned terms)
 {
     (void)hipSetDevice(s->device);
@@ -521,10 +548,13 @@ extern "C" int mdx_compute_forces(mdx_system *s, unsigned terms)
     MDX_CHECK(s, hipMemsetAsync(s->f, 0, sizeof(float) * 3 * s->n, s->stream));
     if ((rc = mdx_search(s))) return rc;
     if ((rc = mdx_launch_prepare(s))) return rc;
-    if (terms & MDX_F_NONBONDED) if ((rc = mdx_launch_nonbonded(s, true))) return rc;
+    if (!(terms & MDX_F_PME) || !s->have_pme) MDX_CHECK(s, hipMemsetAsync(s->f_pme, 0, sizeof(float) * 3 * s->n, s->stream));
+    if ((rc = mdx_fork(s))) return rc;
     if (terms & MDX_F_PME) if ((rc = mdx_launch_pme(s, true))) return rc;
     if ((rc = mdx_launch_bonded(s, true, terms))) return rc;
     if (terms & MDX_F_PULL) if ((rc = mdx_launch_pull(s, false, true))) return rc;
+    if (terms & MDX_F_NONBONDED) if ((rc = mdx_launch_nonbonded(s, true))) return rc;
+    if ((rc = mdx_join(s))) return rc;
     if ((rc = mdx_launch_ke(s, true, true))) return rc;
     if ((rc = mdx_launch_ke(s, false, true))) return rc;
     if ((rc = mdx_launch_finish_energy(s))) return rc;
@@ -642,13 +672,15 @@ extern "C" int mdx_step(mdx_system *s, long long nsteps)
         MDX_CHECK(s, hipMemsetAsync(s->f, 0, sizeof(float) * 3 * s->n, s->stream));
         if (do_search) if ((rc = mdx_search(s))) return rc;
         if ((rc = mdx_launch_prepare(s))) return rc;
-        if ((rc = mdx_launch_nonbonded(s, need_vir))) return rc;
+        if ((rc = mdx_fork(s))) return rc;
         if ((rc = mdx_launch_pme(s, need_vir))) return rc;
         if ((rc = mdx_launch_bonded(s, need_vir, MDX_F_BONDED | MDX_F_POSRES | (s->have_pme ? MDX_F_EXCL : 0)))) return rc;
         if (s->pull_on) {
             const bool log_now = (step % s->pull_nstout == 0);
             if ((rc = mdx_launch_pull(s, log_now, need_vir))) return rc;
         }
+        if ((rc = mdx_launch_nonbonded(s, need_vir))) return rc;
+        if ((rc = mdx_join(s))) return rc;
         if ((rc = mdx_launch_update(s, tc_apply, s->pcoupl == 2, need_vir))) return rc;
         if (need_vir) {
             if ((rc = mdx_launch_ke(s, false, true))) return rc;

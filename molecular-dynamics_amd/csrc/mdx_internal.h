@@ -61,7 +61,11 @@ struct mdx_system {
     std::vector<long long> frame_steps;   // steps of the energy frames not yet popped
     long long pull_log_popped = 0;
     bool pull_reset_pending = false;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // main stream: search, nonbonded, update
+    hipStream_t st_pme = nullptr;      // PME chain (spread, FFTs, solve, gather) overlaps the nonbonded kernel
+    hipStream_t st_bond = nullptr;     // bonded, restraint, exclusion and pull kernels
+    hipEvent_t ev_fork = nullptr, ev_pme = nullptr, ev_bond = nullptr;
+    float *f_pme = nullptr;            // 3N mesh forces (plain stores, so no race with the atomics on f)
     std::string err;
     int n = 0;                    // atoms
     int npad = 0;                 // capacity of sorted arrays (multiple of 64)
@@ -169,6 +173,8 @@ struct mdx_system {
 
 // kernels' host launchers (each returns MDX_OK or an error code)
 int mdx_search(mdx_system *s);
+int mdx_fork(mdx_system *s);
+int mdx_join(mdx_system *s);
 int mdx_launch_prepare(mdx_system *s);
 int mdx_launch_nonbonded(mdx_system *s, bool energy);
 int mdx_launch_pme(mdx_system *s, bool energy);

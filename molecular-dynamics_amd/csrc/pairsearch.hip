@@ -26,9 +26,9 @@ __global__ void k_bin(int n, const float4 *__restrict__ x, const DevState *__res
                       int *__restrict__ atom_slot)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const bool live = i < n;
     const float *h = d->box.h;
-    float4 p = x[i];
+    float4 p = live ? x[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     int nc = (int)floorf(p.z / h[8]);
     p.x -= nc * h[6]; p.y -= nc * h[7]; p.z -= nc * h[8];
     int nb = (int)floorf(p.y / h[4]);
@@ -37,8 +37,22 @@ __global__ void k_bin(int n, const float4 *__restrict__ x, const DevState *__res
     p.x -= na * h[0];
     int cx = min(ncx - 1, max(0, (int)(p.x * ncx / h[0])));
     int cy = min(ncy - 1, max(0, (int)(p.y * ncy / h[4])));
-    const int col = cy * ncx + cx;
-    const int slot = atomicAdd(&col_count[col], 1);
+    const int col = live ? cy * ncx + cx : -1;
+    // neighbouring atoms mostly share a column: one returning atomic per distinct column per wave
+    int slot = 0;
+    unsigned long long todo = __ballot(live);
+    const unsigned long long below = (1ull << (threadIdx.x & 63)) - 1ull;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int lcol = __shfl(col, leader, 64);
+        const unsigned long long same = __ballot(col == lcol) & todo;
+        int base = 0;
+        if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&col_count[lcol], __popcll(same));
+        base = __shfl(base, leader, 64);
+        if (col == lcol && live) slot = base + __popcll(same & below);
+        todo &= ~same;
+    }
+    if (!live) return;
     p.w = __int_as_float(pack_shift(-na, -nb, -nc));
     wrapped[i] = p;
     atom_col[i] = col;
@@ -218,29 +232,35 @@ struct ListArgs {
     float rlist;
 };
 
-#define EBUF 256
+#define EBUF 1024
 
+// One workgroup (4 waves) per i-super-cluster: the waves share the i-atoms in LDS, take the
+// candidate j-super-clusters round-robin and append entries to one LDS buffer, which is flushed
+// once per lattice shift so the entries of a (super-cluster, shift) stay contiguous.
 __global__ __launch_bounds__(256) void k_build_list(ListArgs A)
 {
-    __shared__ float4 xi_sh[4][64];
-    __shared__ int mol_sh[4][64];
-    __shared__ int orig_sh[4][64];
-    __shared__ NbEntry ebuf[4][EBUF];
+    __shared__ float4 xi_sh[64];
+    __shared__ int mol_sh[64];
+    __shared__ int orig_sh[64];
+    __shared__ NbEntry ebuf[EBUF];
+    __shared__ int s_nent, s_start, s_w0;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int sci = blockIdx.x * 4 + wv;
+    const int sci = blockIdx.x;
     const int nsc = A.dro->nsc;
-    if (sci >= nsc) return;
+    if (sci >= nsc) return;                     // uniform for the whole workgroup
     const float rl2 = A.rlist * A.rlist;
     const float *h = A.dro->box.h;
     const float wx = h[0] / A.ncx, wy = h[4] / A.ncy, cz = h[8];
-    xi_sh[wv][lane] = A.xq_s[sci * 64 + lane];
-    mol_sh[wv][lane] = A.molid_s[sci * 64 + lane];
-    orig_sh[wv][lane] = A.perm[sci * 64 + lane];
+    if (threadIdx.x < 64) {
+        xi_sh[lane] = A.xq_s[sci * 64 + lane];
+        mol_sh[lane] = A.molid_s[sci * 64 + lane];
+        orig_sh[lane] = A.perm[sci * 64 + lane];
+    }
+    if (threadIdx.x == 0) s_nent = 0;
     const float4 slo4 = A.sbb_lo[sci], shi4 = A.sbb_hi[sci];
     const int ti = lane & 7, tj = lane >> 3;
     const float4 ilo4 = A.bb_lo[sci * 8 + ti], ihi4 = A.bb_hi[sci * 8 + ti];
-    __builtin_amdgcn_wave_barrier();
-    NbEntry *eb = ebuf[wv];
+    __syncthreads();
 
     for (int s = 0; s < A.nshift; s++) {
         const float4 S = A.shiftvec[s];
@@ -253,7 +273,7 @@ __global__ __launch_bounds__(256) void k_build_list(ListArgs A)
         if (cx0 > cx1 || cy0 > cy1) continue;
         const float3 ilo = make_float3(ilo4.x - S.x, ilo4.y - S.y, ilo4.z - S.z);
         const float3 ihi = make_float3(ihi4.x - S.x, ihi4.y - S.y, ihi4.z - S.z);
-        int nent = 0;
+        int cand = 0;
         for (int cy = cy0; cy <= cy1; cy++)
             for (int cx = cx0; cx <= cx1; cx++) {
                 const int col = cy * A.ncx + cx;
@@ -267,6 +287,7 @@ __global__ __launch_bounds__(256) void k_build_list(ListArgs A)
                     while (m) {
                         const int b = __ffsll((long long)m) - 1;
                         m &= m - 1;
+                        if (((cand++) & 3) != wv) continue;      // this candidate belongs to another wave
                         const int scj = base + b;
                         // cluster level: lane = (i-cluster ti, j-cluster tj)
                         bool okc = bb_dist2(ilo, ihi, A.bb_lo[scj * 8 + tj], A.bb_hi[scj * 8 + tj]) < rl2;
@@ -283,13 +304,13 @@ __global__ __launch_bounds__(256) void k_build_list(ListArgs A)
                             unsigned newim = 0, exb = 0xFF;
                             for (int ci = 0; ci < 8; ci++) {
                                 if (!(im & (1u << ci))) continue;
-                                const float4 xi = xi_sh[wv][ci * 8 + ti];
+                                const float4 xi = xi_sh[ci * 8 + ti];
                                 const float dx = xi.x - S.x - xj.x, dy = xi.y - S.y - xj.y, dz = xi.z - S.z - xj.z;
                                 const bool in = (dx * dx + dy * dy + dz * dz) < rl2;
                                 bool ex = false;
                                 if (central && cjg == sci * 8 + ci) ex = (tj <= ti);   // same cluster: each pair once
-                                if (!ex && molj >= 0 && mol_sh[wv][ci * 8 + ti] == molj) {
-                                    const int oi = orig_sh[wv][ci * 8 + ti];
+                                if (!ex && molj >= 0 && mol_sh[ci * 8 + ti] == molj) {
+                                    const int oi = orig_sh[ci * 8 + ti];
                                     const int e0 = A.excl_start[oi], e1 = A.excl_start[oi + 1];
                                     for (int k = e0; k < e1; k++)
                                         if (A.excl_list[k] == origj) { ex = true; break; }
@@ -306,46 +327,34 @@ __global__ __launch_bounds__(256) void k_build_list(ListArgs A)
                                 if (slot < A.excl_cap) A.exclmask[(size_t)slot * 64 + lane] = (unsigned char)exb;
                                 else { slot = 0; if (lane == 0) atomicOr(&A.d->overflow, 4); }
                             }
-                            if (lane == 0) { eb[nent].cj = cjg; eb[nent].mask = newim | ((unsigned)slot << 8); }
-                            nent++;
-                            if (nent == EBUF) {
-                                // flush a full buffer
-                                int start = 0, w0 = 0;
-                                const int nw = (nent + MDX_NB_CHUNK - 1) / MDX_NB_CHUNK;
-                                if (lane == 0) { start = atomicAdd(&A.d->ncj, nent); w0 = atomicAdd(&A.d->nwork, nw); }
-                                start = __shfl(start, 0, 64); w0 = __shfl(w0, 0, 64);
-                                __builtin_amdgcn_wave_barrier();
-                                if (start + nent <= A.cj_cap && w0 + nw <= A.work_cap) {
-                                    for (int k = lane; k < nent; k += 64) A.cj[start + k] = eb[k];
-                                    for (int k = lane; k < nw; k += 64) {
-                                        NbWork w; w.sci = sci; w.shift = s; w.cj_start = start + k * MDX_NB_CHUNK;
-                                        w.cj_end = min(start + nent, w.cj_start + MDX_NB_CHUNK);
-                                        A.work[w0 + k] = w;
-                                    }
-                                } else if (lane == 0) atomicOr(&A.d->overflow, (start + nent > A.cj_cap) ? 1 : 2);
-                                __builtin_amdgcn_wave_barrier();
-                                nent = 0;
+                            if (lane == 0) {
+                                const int idx = atomicAdd(&s_nent, 1);
+                                if (idx < EBUF) { ebuf[idx].cj = cjg; ebuf[idx].mask = newim | ((unsigned)slot << 8); }
+                                else atomicOr(&A.d->overflow, 32);
                             }
                         }
                     }
                 }
             }
+        __syncthreads();
+        const int nent = min(s_nent, EBUF);
         if (nent) {
-            int start = 0, w0 = 0;
             const int nw = (nent + MDX_NB_CHUNK - 1) / MDX_NB_CHUNK;
-            if (lane == 0) { start = atomicAdd(&A.d->ncj, nent); w0 = atomicAdd(&A.d->nwork, nw); }
-            start = __shfl(start, 0, 64); w0 = __shfl(w0, 0, 64);
-            __builtin_amdgcn_wave_barrier();
+            if (threadIdx.x == 0) { s_start = atomicAdd(&A.d->ncj, nent); s_w0 = atomicAdd(&A.d->nwork, nw); }
+            __syncthreads();
+            const int start = s_start, w0 = s_w0;
             if (start + nent <= A.cj_cap && w0 + nw <= A.work_cap) {
-                for (int k = lane; k < nent; k += 64) A.cj[start + k] = eb[k];
-                for (int k = lane; k < nw; k += 64) {
+                for (int k = threadIdx.x; k < nent; k += 256) A.cj[start + k] = ebuf[k];
+                for (int k = threadIdx.x; k < nw; k += 256) {
                     NbWork w; w.sci = sci; w.shift = s; w.cj_start = start + k * MDX_NB_CHUNK;
                     w.cj_end = min(start + nent, w.cj_start + MDX_NB_CHUNK);
                     A.work[w0 + k] = w;
                 }
-            } else if (lane == 0) atomicOr(&A.d->overflow, (start + nent > A.cj_cap) ? 1 : 2);
-            __builtin_amdgcn_wave_barrier();
+            } else if (threadIdx.x == 0) atomicOr(&A.d->overflow, (start + nent > A.cj_cap) ? 1 : 2);
+            __syncthreads();
+            if (threadIdx.x == 0) s_nent = 0;
         }
+        __syncthreads();
     }
 }
 
@@ -451,7 +460,7 @@ int mdx_search(mdx_system *s)
     A.shiftvec = s->shiftvec; A.nshift = s->nshift; A.central = s->central_shift; A.excl_start = s->excl_start;
     A.excl_list = s->excl_list; A.cj = s->cj; A.cj_cap = s->cj_cap; A.work = s->work; A.work_cap = s->work_cap;
     A.exclmask = s->exclmask; A.excl_cap = s->excl_cap; A.rlist = s->rlist;
-    const int nblk = (s->npad / 64 + 3) / 4;
+    const int nblk = s->npad / 64;
     hipLaunchKernelGGL(k_build_list, dim3(nblk), dim3(256), 0, s->stream, A);
     MDX_CHECK(s, hipGetLastError());
     s->steps_since_search = 0;

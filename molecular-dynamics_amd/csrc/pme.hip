@@ -4,6 +4,8 @@
 // Grid layout: (nx, ny, nz) with z fastest; fractional coordinates s = x . inv(box) so the
 // triclinic dodecahedron needs no special casing; reciprocal vectors m = inv(box) . m'.
 #include "mdx_internal.h"
+#include <algorithm>
+#include <cstdlib>
 
 __device__ __forceinline__ void bspline4(float t, float *w, float *dw)
 {
@@ -35,49 +37,120 @@ __device__ __forceinline__ void frac_index(const DevBox &b, float4 p, int K0, in
     }
 }
 
-// 16 lanes per atom: lane (a = sub>>2 over x, c = sub&3 over z) loops over the 4 y offsets, so the
-// four lanes of a quad add to 4 consecutive floats of one z-row.
-__global__ __launch_bounds__(256) void k_pme_spread(int n, const float4 *__restrict__ x, const DevState *__restrict__ d,
-                                                    int K0, int K1, int K2, float *__restrict__ grid)
+// Continuous (unwrapped) grid coordinates of a position that lies in or near the brick cell.
+__device__ __forceinline__ void grid_coords(const DevBox &b, float4 p, int K0, int K1, int K2, float *u)
 {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    const int atom = g >> 4, sub = g & 15;
-    if (atom >= n) return;
-    const float4 p = x[atom];
-    if (p.w == 0.0f) return;
-    int i0[3]; float t[3];
-    frac_index(d->box, p, K0, K1, K2, i0, t);
-    float wx[4], wy[4], wz[4], dws[4];
-    bspline4(t[0], wx, dws); bspline4(t[1], wy, dws); bspline4(t[2], wz, dws);
-    const int a = sub >> 2, c = sub & 3;
-    int ia = i0[0] + a; if (ia >= K0) ia -= K0;
-    int ic = i0[2] + c; if (ic >= K2) ic -= K2;
-    const float qa = p.w * wx[a] * wz[c];
+    u[0] = K0 * (p.x * b.inv[0] + p.y * b.inv[3] + p.z * b.inv[6]);
+    u[1] = K1 * (p.y * b.inv[4] + p.z * b.inv[7]);
+    u[2] = K2 * (p.z * b.inv[8]);
+}
+__device__ __forceinline__ int pmod(int a, int K) { a %= K; return a < 0 ? a + K : a; }
+
+struct SpreadArgs {
+    int ncx, ncy;
+    const int *col_scstart;
+    const float4 *xq_s;
+    int K0, K1, K2;
+    int T0, T1;          // LDS window per grid plane (x, y)
+    int ppc;             // tile planes per workgroup
+    float delta;         // drift margin in nm used for the window origins
+    float *grid;
+};
+
+// Charge spreading with one workgroup per (pair-search column, slab of grid planes).
+// The grid is stored x-fastest: grid[(iz*K1 + iy)*K0 + ix]. In a lower-triangular box the x-run
+// touched by a compact group of atoms is contiguous for fixed (iy, iz), while the run along z is
+// not (the c vector is tilted), so windows are kept per plane: window origin (ox, oy) follows the
+// shear of the cell with the plane's height. Contributions are accumulated in LDS with ds_add_f32
+// and flushed once with row-contiguous float atomics; a contribution that falls outside its
+// window (an atom that drifted far since the last pair search) goes straight to global memory.
+__global__ __launch_bounds__(256) void k_pme_spread_col(SpreadArgs A, const DevState *__restrict__ d)
+{
+    extern __shared__ float tile[];
+    int *ox = (int *)(tile + A.ppc * A.T1 * A.T0);
+    int *oy = ox + A.ppc;
+    const int col = blockIdx.x;
+    const int a0 = A.col_scstart[col] * 64, a1 = A.col_scstart[col + 1] * 64;
+    if (a0 == a1) return;
+    const DevBox &bx = d->box;
+    const int tp0 = blockIdx.y * A.ppc;
+    const float wx = bx.h[0] / A.ncx, wy = bx.h[4] / A.ncy;
+    const int cxi = col % A.ncx, cyi = col / A.ncx;
+    const float x_lo = cxi * wx - A.delta, x_hi = (cxi + 1) * wx + A.delta;
+    const float y_lo = cyi * wy - A.delta, y_hi = (cyi + 1) * wy + A.delta;
+    for (int p = threadIdx.x; p < A.ppc; p += blockDim.x) {
+        const int tp = tp0 + p;
+        // atoms contributing to tile plane tp have floor(u_z) in [tp-6, tp-3]
+        const float z_lo = (tp - 6) / (A.K2 * bx.inv[8]) - A.delta, z_hi = (tp - 2) / (A.K2 * bx.inv[8]) + A.delta;
+        const float ux = A.K0 * (x_lo * bx.inv[0] + fminf(y_lo * bx.inv[3], y_hi * bx.inv[3]) + fminf(z_lo * bx.inv[6], z_hi * bx.inv[6]));
+        const float uy = A.K1 * (y_lo * bx.inv[4] + fminf(z_lo * bx.inv[7], z_hi * bx.inv[7]));
+        ox[p] = (int)floorf(ux); oy[p] = (int)floorf(uy);
+    }
+    const int nt = A.ppc * A.T1 * A.T0;
+    for (int k = threadIdx.x; k < nt; k += blockDim.x) tile[k] = 0.0f;
+    __syncthreads();
+    const int nwork = (a1 - a0) * 4;
+    for (int w = threadIdx.x; w < nwork; w += blockDim.x) {
+        const float4 p = A.xq_s[a0 + (w >> 2)];
+        if (p.w == 0.0f) continue;
+        float u[3];
+        grid_coords(bx, p, A.K0, A.K1, A.K2, u);
+        const int px = (int)floorf(u[0]), py = (int)floorf(u[1]), pz = (int)floorf(u[2]);
+        const int c = w & 3;
+        const int tp = pz + c + 3;
+        if (tp < tp0 || tp >= tp0 + A.ppc) continue;
+        float wxs[4], wys[4], wzs[4], dws[4];
+        bspline4(u[0] - px, wxs, dws); bspline4(u[1] - py, wys, dws); bspline4(u[2] - pz, wzs, dws);
+        const float wzc = c == 0 ? wzs[0] : (c == 1 ? wzs[1] : (c == 2 ? wzs[2] : wzs[3]));
+        const int pl = tp - tp0;
+        const int rx0 = px - ox[pl], ry0 = py - oy[pl];
+        const float qz = p.w * wzc;
+        if (rx0 >= 0 && rx0 + 3 < A.T0 && ry0 >= 0 && ry0 + 3 < A.T1) {
+            float *t = tile + (pl * A.T1 + ry0) * A.T0 + rx0;
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-        int ib = i0[1] + b; if (ib >= K1) ib -= K1;
-        atomicAdd(&grid[((size_t)ia * K1 + ib) * K2 + ic], qa * wy[b]);
+            for (int b = 0; b < 4; b++)
+#pragma unroll
+                for (int a = 0; a < 4; a++) atomicAdd(&t[b * A.T0 + a], qz * wys[b] * wxs[a]);
+        } else {
+            const int gz = pmod(pz + c, A.K2);
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int gy = pmod(py + b, A.K1);
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+                    atomicAdd(&A.grid[((size_t)gz * A.K1 + gy) * A.K0 + pmod(px + a, A.K0)], qz * wys[b] * wxs[a]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nt; k += blockDim.x) {
+        const float v = tile[k];
+        if (v == 0.0f) continue;
+        const int rx = k % A.T0, ry = (k / A.T0) % A.T1, pl = k / (A.T0 * A.T1);
+        const int gz = pmod(tp0 + pl - 3, A.K2), gy = pmod(oy[pl] + ry, A.K1), gx = pmod(ox[pl] + rx, A.K0);
+        atomicAdd(&A.grid[((size_t)gz * A.K1 + gy) * A.K0 + gx], v);
     }
 }
 
 // Multiply the transformed grid by the Ewald influence function; optionally accumulate the
-// reciprocal energy and virial. cgrid is (K0, K1, K2/2+1) complex.
+// reciprocal energy and virial. cgrid is (K2, K1, K0/2+1) complex (x fastest).
 template <bool ENERGY>
 __global__ __launch_bounds__(256) void k_pme_solve(float2 *__restrict__ cgrid, const DevState *__restrict__ d, DevState *__restrict__ dw,
                                                    int K0, int K1, int K2, const float *__restrict__ bm0,
                                                    const float *__restrict__ bm1, const float *__restrict__ bm2, float beta)
 {
     __shared__ double red[16];
-    const int K2c = K2 / 2 + 1;
-    const size_t total = (size_t)K0 * K1 * K2c;
+    const int K0c = K0 / 2 + 1;
+    const size_t total = (size_t)K2 * K1 * K0c;
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     double e = 0.0, v[6] = { 0, 0, 0, 0, 0, 0 };
     if (g < total) {
-        const int k2 = (int)(g % K2c);
-        const int k1 = (int)((g / K2c) % K1);
-        const int k0 = (int)(g / ((size_t)K2c * K1));
-        // signed frequencies; the Nyquist index of an even dimension counts as -K/2
-        const int m0 = (k0 < (K0 + 1) / 2) ? k0 : k0 - K0;
+        const int k0 = (int)(g % K0c);
+        const int k1 = (int)((g / K0c) % K1);
+        const int k2 = (int)(g / ((size_t)K0c * K1));
+        // x is the halved dimension: m0 = k0 >= 0 (the Nyquist term counts as +K0/2); y and z are signed
+        // with the Nyquist index of an even dimension counted as -K/2 (the enumeration GROMACS uses)
+        const int m0 = k0;
         const int m1 = (k1 < (K1 + 1) / 2) ? k1 : k1 - K1;
         const int m2 = (k2 < (K2 + 1) / 2) ? k2 : k2 - K2;
         if (m0 != 0 || m1 != 0 || m2 != 0) {
@@ -92,8 +165,8 @@ __global__ __launch_bounds__(256) void k_pme_solve(float2 *__restrict__ cgrid, c
             const float eterm = MDX_ONE_4PI_EPS0 * __expf(-fac * msq) / denom;
             float2 c = cgrid[g];
             if (ENERGY) {
-                // half-complex storage: planes 0 < k2 < K2/2 (and K2 odd: all k2>0) stand for two terms
-                const float mult = (k2 == 0 || (K2 % 2 == 0 && k2 == K2 / 2)) ? 1.0f : 2.0f;
+                // half-complex storage along x: 0 < k0 < K0/2 (K0 odd: all k0 > 0) stands for two terms
+                const float mult = (k0 == 0 || (K0 % 2 == 0 && k0 == K0 / 2)) ? 1.0f : 2.0f;
                 const double em = 0.5 * mult * (double)eterm * ((double)c.x * c.x + (double)c.y * c.y);
                 e = em;
                 const double vf = 2.0 * (1.0 + fac * msq) / msq;
@@ -136,13 +209,13 @@ __global__ __launch_bounds__(256) void k_pme_gather(int n, const float4 *__restr
             frac_index(d->box, p, K0, K1, K2, i0, t);
             float wx[4], wy[4], wz[4], dx[4], dy[4], dz[4];
             bspline4(t[0], wx, dx); bspline4(t[1], wy, dy); bspline4(t[2], wz, dz);
-            const int a = sub >> 2, c = sub & 3;
+            const int c = sub >> 2, a = sub & 3;
             int ia = i0[0] + a; if (ia >= K0) ia -= K0;
             int ic = i0[2] + c; if (ic >= K2) ic -= K2;
 #pragma unroll
             for (int b = 0; b < 4; b++) {
                 int ib = i0[1] + b; if (ib >= K1) ib -= K1;
-                const float ph = phi[((size_t)ia * K1 + ib) * K2 + ic];
+                const float ph = phi[((size_t)ic * K1 + ib) * K0 + ia];
                 gx = fmaf(dx[a] * wy[b] * wz[c], ph, gx);
                 gy = fmaf(wx[a] * dy[b] * wz[c], ph, gy);
                 gz = fmaf(wx[a] * wy[b] * dz[c], ph, gz);
@@ -153,13 +226,13 @@ __global__ __launch_bounds__(256) void k_pme_gather(int n, const float4 *__restr
     for (int o = 8; o > 0; o >>= 1) {
         gx += __shfl_xor(gx, o, 64); gy += __shfl_xor(gy, o, 64); gz += __shfl_xor(gz, o, 64);
     }
-    if (atom < n && sub == 0 && q != 0.0f) {
+    if (atom < n && sub == 0) {
         const float *iv = d->box.inv;
         const float ux = gx * K0, uy = gy * K1, uz = gz * K2;
-        // F_e = -q sum_d dE/du_d K_d inv[e][d]
-        f[3 * atom + 0] += -q * (ux * iv[0] + uy * iv[1] + uz * iv[2]);
-        f[3 * atom + 1] += -q * (ux * iv[3] + uy * iv[4] + uz * iv[5]);
-        f[3 * atom + 2] += -q * (ux * iv[6] + uy * iv[7] + uz * iv[8]);
+        // F_e = -q sum_d dE/du_d K_d inv[e][d]; every atom is written (zero for uncharged ones)
+        f[3 * atom + 0] = -q * (ux * iv[0] + uy * iv[1] + uz * iv[2]);
+        f[3 * atom + 1] = -q * (ux * iv[3] + uy * iv[4] + uz * iv[5]);
+        f[3 * atom + 2] = -q * (ux * iv[6] + uy * iv[7] + uz * iv[8]);
     }
 }
 
@@ -185,7 +258,7 @@ int mdx_pme_init(mdx_system *s)
     mdx_pme_free(s);
     if (s->K[0] <= 0) { s->have_pme = false; return MDX_OK; }
     const size_t nr = (size_t)s->K[0] * s->K[1] * s->K[2];
-    const size_t ncx = (size_t)s->K[0] * s->K[1] * (s->K[2] / 2 + 1);
+    const size_t ncx = (size_t)s->K[2] * s->K[1] * (s->K[0] / 2 + 1);
     MDX_CHECK(s, hipMalloc(&s->grid, sizeof(float) * nr));
     MDX_CHECK(s, hipMalloc(&s->cgrid, sizeof(float2) * ncx));
     for (int d = 0; d < 3; d++) {
@@ -194,13 +267,13 @@ int mdx_pme_init(mdx_system *s)
         MDX_CHECK(s, hipMalloc(&s->bmod[d], sizeof(float) * s->K[d]));
         MDX_CHECK(s, hipMemcpy(s->bmod[d], bm.data(), sizeof(float) * s->K[d], hipMemcpyHostToDevice));
     }
-    if (hipfftPlan3d(&s->plan_r2c, s->K[0], s->K[1], s->K[2], HIPFFT_R2C) != HIPFFT_SUCCESS ||
-        hipfftPlan3d(&s->plan_c2r, s->K[0], s->K[1], s->K[2], HIPFFT_C2R) != HIPFFT_SUCCESS) {
+    if (hipfftPlan3d(&s->plan_r2c, s->K[2], s->K[1], s->K[0], HIPFFT_R2C) != HIPFFT_SUCCESS ||
+        hipfftPlan3d(&s->plan_c2r, s->K[2], s->K[1], s->K[0], HIPFFT_C2R) != HIPFFT_SUCCESS) {
         s->err = "hipfftPlan3d failed";
         return MDX_ERR_HIP;
     }
-    hipfftSetStream(s->plan_r2c, s->stream);
-    hipfftSetStream(s->plan_c2r, s->stream);
+    hipfftSetStream(s->plan_r2c, s->st_pme);
+    hipfftSetStream(s->plan_c2r, s->st_pme);
     s->have_pme = true;
     return MDX_OK;
 }
@@ -220,18 +293,38 @@ int mdx_launch_pme(mdx_system *s, bool energy)
     if (!s->have_pme) return MDX_OK;
     const int K0 = s->K[0], K1 = s->K[1], K2 = s->K[2];
     const size_t nr = (size_t)K0 * K1 * K2;
-    const size_t ncx = (size_t)K0 * K1 * (K2 / 2 + 1);
-    MDX_CHECK(s, hipMemsetAsync(s->grid, 0, sizeof(float) * nr, s->stream));
+    const size_t ncx = (size_t)K2 * K1 * (K0 / 2 + 1);
+    MDX_CHECK(s, hipMemsetAsync(s->grid, 0, sizeof(float) * nr, s->st_pme));
     const int nb = (int)(((size_t)s->n * 16 + 255) / 256);
-    hipLaunchKernelGGL(k_pme_spread, dim3(nb), dim3(256), 0, s->stream, s->n, s->x, s->d, K0, K1, K2, s->grid);
+    {
+        // window sizes from the column geometry (host copy of the box; a drift margin covers the rest)
+        const double *bxd = s->h->boxd;
+        const double inv0 = 1.0 / bxd[0], inv4 = 1.0 / bxd[4], inv8 = 1.0 / bxd[8];
+        const double inv3 = -bxd[3] * inv0 * inv4, inv6 = (bxd[3] * bxd[7] - bxd[4] * bxd[6]) * inv0 * inv4 * inv8, inv7 = -bxd[7] * inv4 * inv8;
+        const double delta = 0.12;
+        const double wx = bxd[0] / s->ncx + 2 * delta, wy = bxd[4] / s->ncy + 2 * delta, wz = 4.0 / (K2 * inv8) + 2 * delta;
+        SpreadArgs A;
+        A.ncx = s->ncx; A.ncy = s->ncy; A.col_scstart = s->col_scstart; A.xq_s = s->xq_s; A.K0 = K0; A.K1 = K1; A.K2 = K2;
+        A.T0 = std::min(K0, (int)ceil(K0 * (inv0 * wx + fabs(inv3) * wy + fabs(inv6) * wz)) + 5);
+        A.T1 = std::min(K1, (int)ceil(K1 * (inv4 * wy + fabs(inv7) * wz)) + 5);
+        const int planes = K2 + 8;
+        // slabs of planes so that a tile stays below ~48 KB and the launch has enough workgroups
+        int nchunk = 1;
+        while ((size_t)((planes + nchunk - 1) / nchunk) * A.T0 * A.T1 * 4 > 48 * 1024 || (s->ncx * s->ncy * nchunk < 512 && nchunk < 8)) nchunk++;
+        A.ppc = (planes + nchunk - 1) / nchunk;
+        A.delta = (float)delta; A.grid = s->grid;
+        if (getenv("MDX_PME_NOTILE")) { A.T0 = 4; A.T1 = 4; }
+        const size_t lds = (size_t)A.ppc * A.T0 * A.T1 * 4 + (size_t)A.ppc * 8;
+        hipLaunchKernelGGL(k_pme_spread_col, dim3(s->ncx * s->ncy, nchunk), dim3(256), lds, s->st_pme, A, s->d);
+    }
     if (hipfftExecR2C(s->plan_r2c, s->grid, (hipfftComplex *)s->cgrid) != HIPFFT_SUCCESS) { s->err = "hipfftExecR2C failed"; return MDX_ERR_HIP; }
     const int nbs = (int)((ncx + 255) / 256);
     if (energy)
-        hipLaunchKernelGGL(k_pme_solve<true>, dim3(nbs), dim3(256), 0, s->stream, s->cgrid, s->d, s->d, K0, K1, K2, s->bmod[0], s->bmod[1], s->bmod[2], s->beta);
+        hipLaunchKernelGGL(k_pme_solve<true>, dim3(nbs), dim3(256), 0, s->st_pme, s->cgrid, s->d, s->d, K0, K1, K2, s->bmod[0], s->bmod[1], s->bmod[2], s->beta);
     else
-        hipLaunchKernelGGL(k_pme_solve<false>, dim3(nbs), dim3(256), 0, s->stream, s->cgrid, s->d, s->d, K0, K1, K2, s->bmod[0], s->bmod[1], s->bmod[2], s->beta);
+        hipLaunchKernelGGL(k_pme_solve<false>, dim3(nbs), dim3(256), 0, s->st_pme, s->cgrid, s->d, s->d, K0, K1, K2, s->bmod[0], s->bmod[1], s->bmod[2], s->beta);
     if (hipfftExecC2R(s->plan_c2r, (hipfftComplex *)s->cgrid, s->grid) != HIPFFT_SUCCESS) { s->err = "hipfftExecC2R failed"; return MDX_ERR_HIP; }
-    hipLaunchKernelGGL(k_pme_gather, dim3(nb), dim3(256), 0, s->stream, s->n, s->x, s->d, K0, K1, K2, s->grid, s->f);
+    hipLaunchKernelGGL(k_pme_gather, dim3(nb), dim3(256), 0, s->st_pme, s->n, s->x, s->d, K0, K1, K2, s->grid, s->f_pme);
     MDX_CHECK(s, hipGetLastError());
     return MDX_OK;
 }

@@ -9,7 +9,7 @@
 // v' = lambda_g * (v + f/m dt) - dt * M v  (M: Parrinello-Rahman coupling matrix, zero otherwise);
 // xp = x + v' dt. Total force = original-order array + sorted nonbonded buffer.
 __global__ __launch_bounds__(256) void k_leapfrog(int n, const float4 *__restrict__ x, float4 *__restrict__ xp,
-                                                  float4 *__restrict__ v, const float *__restrict__ f,
+                                                  float4 *__restrict__ v, const float *__restrict__ f, const float *__restrict__ f_pme,
                                                   const float *__restrict__ f_s, const int *__restrict__ sorted_of,
                                                   const int *__restrict__ tcgrp, const DevState *__restrict__ d, float dt,
                                                   int use_lambda, int use_pr)
@@ -19,7 +19,8 @@ __global__ __launch_bounds__(256) void k_leapfrog(int n, const float4 *__restric
     const float4 xi = x[i];
     float4 vi = v[i];
     const int g = sorted_of[i];
-    const float fx = f[3 * i] + f_s[3 * g], fy = f[3 * i + 1] + f_s[3 * g + 1], fz = f[3 * i + 2] + f_s[3 * g + 2];
+    const float fx = f[3 * i] + f_pme[3 * i] + f_s[3 * g], fy = f[3 * i + 1] + f_pme[3 * i + 1] + f_s[3 * g + 1],
+                fz = f[3 * i + 2] + f_pme[3 * i + 2] + f_s[3 * g + 2];
     const float im = vi.w;
     float lam = 1.0f;
     if (use_lambda) lam = (float)d->lambda[tcgrp[i]];
@@ -396,12 +397,12 @@ __global__ void k_comm_sub(int n, float4 *__restrict__ v, const DevState *__rest
     v[i] = vi;
 }
 
-__global__ void k_merge_forces(int n, const float *__restrict__ f, const float *__restrict__ f_s,
+__global__ void k_merge_forces(int n, const float *__restrict__ f, const float *__restrict__ f_pme, const float *__restrict__ f_s,
                                const int *__restrict__ sorted_of, float *__restrict__ out, int have_sorted)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float a = f[3 * i], b = f[3 * i + 1], c = f[3 * i + 2];
+    float a = f[3 * i] + f_pme[3 * i], b = f[3 * i + 1] + f_pme[3 * i + 1], c = f[3 * i + 2] + f_pme[3 * i + 2];
     if (have_sorted) { const int g = sorted_of[i]; a += f_s[3 * g]; b += f_s[3 * g + 1]; c += f_s[3 * g + 2]; }
     out[3 * i] = a; out[3 * i + 1] = b; out[3 * i + 2] = c;
 }
@@ -409,7 +410,7 @@ __global__ void k_merge_forces(int n, const float *__restrict__ f, const float *
 int mdx_launch_update(mdx_system *s, bool do_tc, bool do_pr, bool virial)
 {
     const int nb = (s->n + 255) / 256;
-    hipLaunchKernelGGL(k_leapfrog, dim3(nb), dim3(256), 0, s->stream, s->n, s->x, s->xp, s->v, s->f, s->f_s, s->sorted_of,
+    hipLaunchKernelGGL(k_leapfrog, dim3(nb), dim3(256), 0, s->stream, s->n, s->x, s->xp, s->v, s->f, s->f_pme, s->f_s, s->sorted_of,
                        s->tcgrp, s->d, s->dt, do_tc ? 1 : 0, do_pr ? 1 : 0);
     const float inv_dt = 1.0f / s->dt;
     if (s->nsettle > 0) {
@@ -504,7 +505,7 @@ int mdx_launch_comm(mdx_system *s)
 int mdx_launch_merge_forces(mdx_system *s, float *out3n)
 {
     const int nb = (s->n + 255) / 256;
-    hipLaunchKernelGGL(k_merge_forces, dim3(nb), dim3(256), 0, s->stream, s->n, s->f, s->f_s, s->sorted_of, out3n, 1);
+    hipLaunchKernelGGL(k_merge_forces, dim3(nb), dim3(256), 0, s->stream, s->n, s->f, s->f_pme, s->f_s, s->sorted_of, out3n, 1);
     MDX_CHECK(s, hipGetLastError());
     return MDX_OK;
 }

@@ -146,21 +146,29 @@ def pme_recip(x, q, box, beta, grid, order=4):
     xa, xp = _d(x); qa, qp = _d(q); ra, rp = _d(recip)
     Q = np.zeros((nx, ny, nz))
     lib().orc_pme_spread(n, xp, qp, rp, nx, ny, nz, Q.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
-    Fq = np.fft.fftn(Q)
-    mi = [np.fft.fftfreq(k, 1.0 / k) for k in (nx, ny, nz)]
-    M = np.stack(np.meshgrid(*mi, indexing="ij"), -1)           # integer m'
+    # Real-to-complex transform with x as the halved dimension and frequencies
+    #   m_x = k_x >= 0 (including +K_x/2),  m_y, m_z signed with the Nyquist index counted negative,
+    # which is how GROMACS' solve step enumerates the half-complex grid [GMX-doc]. In a triclinic
+    # cell the sign given to a Nyquist frequency changes |m|^2, so this is part of the convention.
+    Fq = np.fft.rfftn(np.ascontiguousarray(Q.transpose(2, 1, 0)))      # (nz, ny, nx/2+1)
+
+    def signed(k, K):
+        return np.where(k < (K + 1) // 2, k, k - K)
+    k2 = np.arange(nz)[:, None, None]; k1 = np.arange(ny)[None, :, None]; k0 = np.arange(nx // 2 + 1)[None, None, :]
+    M = np.stack(np.broadcast_arrays(k0, signed(k1, ny), signed(k2, nz)), -1).astype(float)   # (.., 3) = (mx', my', mz')
     mv = M @ recip.T
     m2 = (mv * mv).sum(-1)
     m2[0, 0, 0] = 1.0
-    B = 1.0 / (_bspline_moduli(nx)[:, None, None] * _bspline_moduli(ny)[None, :, None] * _bspline_moduli(nz)[None, None, :])
+    B = 1.0 / (_bspline_moduli(nx)[k0] * _bspline_moduli(ny)[k1] * _bspline_moduli(nz)[k2])
     G = ONE_4PI_EPS0 / (np.pi * V) * np.exp(-np.pi ** 2 * m2 / beta ** 2) / m2 * B
     G[0, 0, 0] = 0.0
-    em = 0.5 * G * np.abs(Fq) ** 2
+    mult = np.where((k0 == 0) | ((nx % 2 == 0) & (k0 == nx // 2)), 1.0, 2.0)
+    em = 0.5 * mult * G * np.abs(Fq) ** 2
     E = em.sum()
     fac = 2 * (1 + np.pi ** 2 * m2 / beta ** 2) / m2
-    vir = -0.5 * (E * np.eye(3) - np.einsum("xyz,xyza,xyzb->ab", em * fac, mv, mv))
-    phi = np.real(np.fft.ifftn(G * Fq)) * (nx * ny * nz)
-    phi = np.ascontiguousarray(phi)
+    vir = -0.5 * (E * np.eye(3) - np.einsum("zyx,zyxa,zyxb->ab", em * fac, mv, mv))
+    phi = np.fft.irfftn(G * Fq, s=(nz, ny, nx), axes=(0, 1, 2)) * (nx * ny * nz)
+    phi = np.ascontiguousarray(phi.transpose(2, 1, 0))
     F = np.zeros((n, 3))
     lib().orc_pme_gather(n, xp, qp, rp, nx, ny, nz, phi.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
                          F.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
