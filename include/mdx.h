@@ -167,6 +167,14 @@ long long mdx_pop_pull_records(mdx_system *sys, double *out, long long max_recor
 /* Time the nonbonded kernel with HIP events on the handle's stream (bench only). */
 int mdx_enable_kernel_timing(mdx_system *sys, int on);
 int mdx_get_kernel_timing(mdx_system *sys, double *nb_ms_total, long long *nb_launches);
+/* Diagnostics (no counterpart in the reference): time `iters` back-to-back launches of the
+ * nonbonded kernel on the current pair list; select a kernel variant (key 1: 1 or 2). */
+int mdx_debug_time_nonbonded(mdx_system *sys, int energy, int iters, double *avg_ms);
+int mdx_debug_set(mdx_system *sys, int key, int value);
+/* Average time (ms) of `iters` back-to-back runs of one stage on its own stream: 1 pair search,
+ * 2 PME chain, 3 bonded + exclusion kernels, 4 update + constraints, 5 prepare, 6 PME spread.
+ * The state is not meaningful afterwards (diagnostic only). */
+int mdx_debug_time_stage(mdx_system *sys, int stage, int iters, double *avg_ms);
 
 #ifdef __cplusplus
 }

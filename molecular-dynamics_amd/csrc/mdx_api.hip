@@ -75,7 +75,7 @@ extern "C" mdx_system *mdx_create(int device, int natoms)
     A(&s->bb_lo, s->npad / 8); A(&s->bb_hi, s->npad / 8); A(&s->sbb_lo, s->npad / 64); A(&s->sbb_hi, s->npad / 64);
     A(&s->col_count, s->ncol_cap + 1); A(&s->col_astart, s->ncol_cap + 1); A(&s->col_scstart, s->ncol_cap + 1); A(&s->col_atoms, n);
     A(&s->atom_col, n); A(&s->atom_slot, n); A(&s->wrapped, n);
-    A(&s->cj, s->cj_cap); A(&s->work, s->work_cap); A(&s->exclmask, (size_t)s->excl_cap * 64);
+    A(&s->cj, s->cj_cap); A(&s->work, s->work_cap); A(&s->work_order, s->work_cap); A(&s->exclmask, (size_t)s->excl_cap * 64);
     A(&s->shift_ijk, MDX_MAX_SHIFTS); A(&s->shiftvec, MDX_MAX_SHIFTS);
     A(&s->excl_start, n + 1); A(&s->excl_list, 1); A(&s->d_tc, 3 * MDX_MAX_TC);
     A(&s->d, 1);
@@ -106,7 +106,7 @@ extern "C" void mdx_destroy(mdx_system *s)
     mdx_pme_free(s);
     void *ptrs[] = { s->x, s->xp, s->v, s->f, s->f_pme, s->lj, s->molid, s->tcgrp, s->excl_start, s->excl_list, s->excl_pairs, s->xq_s, s->lj_s,
                      s->f_s, s->perm, s->perm_src, s->shift_s, s->molid_s, s->sorted_of, s->bb_lo, s->bb_hi, s->sbb_lo, s->sbb_hi,
-                     s->col_count, s->col_astart, s->col_scstart, s->col_atoms, s->atom_col, s->atom_slot, s->wrapped, s->cj, s->work,
+                     s->col_count, s->col_astart, s->col_scstart, s->col_atoms, s->atom_col, s->atom_slot, s->wrapped, s->cj, s->work, s->work_order,
                      s->exclmask, s->shift_ijk, s->shiftvec, s->bond_ij, s->bond_p, s->angle_ijk, s->angle_p, s->dih_ijkl, s->dih_p,
                      s->pair_ij, s->pair_p, s->posres_idx, s->posres_ref, s->posres_k, s->settle_idx, s->cons_ij, s->cons_len,
                      s->comp_start, s->d_tc, s->pull_idx[0], s->pull_idx[1], s->d };
@@ -673,13 +673,14 @@ extern "C" int mdx_step(mdx_system *s, long long nsteps)
         if (do_search) if ((rc = mdx_search(s))) return rc;
         if ((rc = mdx_launch_prepare(s))) return rc;
         if ((rc = mdx_fork(s))) return rc;
+        // the nonbonded kernel is the critical path: enqueue it first, the side streams fill in
+        if ((rc = mdx_launch_nonbonded(s, need_vir))) return rc;
         if ((rc = mdx_launch_pme(s, need_vir))) return rc;
         if ((rc = mdx_launch_bonded(s, need_vir, MDX_F_BONDED | MDX_F_POSRES | (s->have_pme ? MDX_F_EXCL : 0)))) return rc;
         if (s->pull_on) {
             const bool log_now = (step % s->pull_nstout == 0);
             if ((rc = mdx_launch_pull(s, log_now, need_vir))) return rc;
         }
-        if ((rc = mdx_launch_nonbonded(s, need_vir))) return rc;
         if ((rc = mdx_join(s))) return rc;
         if ((rc = mdx_launch_update(s, tc_apply, s->pcoupl == 2, need_vir))) return rc;
         if (need_vir) {
@@ -741,4 +742,43 @@ extern "C" long long mdx_pop_pull_records(mdx_system *s, double *out, long long 
     for (long long k = 0; k < n; k++) memcpy(out + 4 * k, s->pull_log + 4 * ((start + k) % s->pull_log_cap), sizeof(double) * 4);
     s->pull_log_popped = start + n;
     return n;
+}
+
+// Diagnostic: average time of `iters` back-to-back runs of one stage of the step on its own
+// stream, measured with HIP events. stage 1 pair search, 2 PME chain, 3 bonded + exclusion
+// kernels, 4 update + constraints, 5 prepare, 6 PME spread only (dbg bits select ablations).
+extern "C" int mdx_debug_time_stage(mdx_system *s, int stage, int iters, double *avg_ms)
+{
+    (void)hipSetDevice(s->device);
+    int rc = sync_and_check(s); if (rc) return rc;
+    MDX_CHECK(s, hipDeviceSynchronize());
+    hipStream_t st = s->stream;
+    if (stage == 2 || stage == 6) st = s->st_pme;
+    if (stage == 3) st = s->st_bond;
+    hipEvent_t a, b;
+    MDX_CHECK(s, hipEventCreate(&a)); MDX_CHECK(s, hipEventCreate(&b));
+    const int saved = s->dbg;
+    if (stage == 6) s->dbg |= 256;
+    auto run = [&]() -> int {
+        switch (stage) {
+        case 1: return mdx_search(s);
+        case 2: case 6: return mdx_launch_pme(s, false);
+        case 3: return mdx_launch_bonded(s, false, MDX_F_BONDED | MDX_F_POSRES | MDX_F_EXCL);
+        case 4: { int r = mdx_launch_update(s, false, false, false); float4 *t = s->x; s->x = s->xp; s->xp = t; return r; }
+        case 5: return mdx_launch_prepare(s);
+        default: s->err = "mdx_debug_time_stage: unknown stage"; return MDX_ERR_ARG;
+        }
+    };
+    rc = run();
+    MDX_CHECK(s, hipEventRecord(a, st));
+    for (int i = 0; i < iters && rc == MDX_OK; i++) rc = run();
+    MDX_CHECK(s, hipEventRecord(b, st));
+    MDX_CHECK(s, hipEventSynchronize(b));
+    float ms = 0.0f;
+    MDX_CHECK(s, hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    s->dbg = saved;
+    MDX_CHECK(s, hipDeviceSynchronize());
+    if (avg_ms) *avg_ms = ms / (iters > 0 ? iters : 1);
+    return rc;
 }

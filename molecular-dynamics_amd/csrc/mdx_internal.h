@@ -48,6 +48,7 @@ struct DevState {
     long long step;
     // pair counters of the last energy step: non-excluded pairs with r < rc, and those with LJ
     unsigned long long npairs_rc, npairs_lj;
+    int work_head[8];             // per-queue dequeue counters of the nonbonded kernel (cleared every step)
 };
 
 struct NbEntry { int cj; unsigned int mask; };        // mask: bits 0-7 i-cluster mask, bits 8.. exclusion slot
@@ -61,6 +62,8 @@ struct mdx_system {
     std::vector<long long> frame_steps;   // steps of the energy frames not yet popped
     long long pull_log_popped = 0;
     bool pull_reset_pending = false;
+    int dbg = 0;                       // diagnostic ablation bits (mdx_debug_set key 2)
+    int nb_variant = 2;                // 1: first-generation kernel, 2: prefetching kernel with rational Ewald correction
     hipStream_t stream = nullptr;      // main stream: search, nonbonded, update
     hipStream_t st_pme = nullptr;      // PME chain (spread, FFTs, solve, gather) overlaps the nonbonded kernel
     hipStream_t st_bond = nullptr;     // bonded, restraint, exclusion and pull kernels
@@ -100,6 +103,7 @@ struct mdx_system {
     // lists
     NbEntry *cj = nullptr; int cj_cap = 0;
     NbWork *work = nullptr; int work_cap = 0;
+    int *work_order = nullptr;    // unit indices by descending tile count
     unsigned char *exclmask = nullptr; int excl_cap = 0;
     int nshift = 0, central_shift = 0;
     int3 *shift_ijk = nullptr;    // device

@@ -12,7 +12,7 @@
 // (max relative error 3.5e-7 in float32 on 0 <= z <= 4.4).
 __device__ __forceinline__ float mdx_erfcx_poly(float z)
 {
-    const float t = __frcp_rn(fmaf(0.41f, z, 1.0f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.41f, z, 1.0f));
     float p = 7.959749251e-02f;
     p = fmaf(p, t, -3.893341305e-01f);
     p = fmaf(p, t, 6.172475282e-01f);

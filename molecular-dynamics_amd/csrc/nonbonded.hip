@@ -11,10 +11,13 @@
 // Pair arithmetic: F/r = [4 eps (12 s6^2 - 6 s6) + qq (erfc(br) + 2/sqrt(pi) br exp(-b^2 r^2)) / r] / r^2
 // with Lorentz-Berthelot sigma/eps from per-atom (sigma/2, 2 sqrt(eps)) so no type table gather.
 #include "mdx_internal.h"
+#include <cstdlib>
+#include <cstddef>
 
 struct NbArgs {
     const DevState *d;
     const NbWork *work;
+    const int *order;            // work units by descending cost
     const NbEntry *cj;
     const unsigned char *exclmask;
     const float4 *xq_s;
@@ -52,8 +55,8 @@ __global__ __launch_bounds__(256) void k_nonbonded(NbArgs A)
     const float rc2 = A.rc2, beta = A.beta;
     const float nb2l2e = -beta * beta * 1.4426950408889634f; // exp(-b^2 r^2) = exp2(nb2l2e * r2)
   for (int unit = blockIdx.x * 4 + (threadIdx.x >> 6); unit < nwork; unit += nwaves) {
-    const NbWork w = A.work[unit];
-    const float4 S = A.shiftvec[w.shift];
+    const NbWork w = A.work[A.order[unit]];
+    const float4 S = A.shiftvec[w.shift & 0xFF];
     float xi[8], yi[8], zi[8], qi[8], hsi[8], sei[8];
     float fix[8], fiy[8], fiz[8];
 #pragma unroll
@@ -162,10 +165,185 @@ __global__ __launch_bounds__(256) void k_nonbonded(NbArgs A)
     }
 }
 
+// g(w) = (erf(z)/z - 2/sqrt(pi) exp(-w))/w, w = z^2: rational fit of degree (5,5) on 0 <= w <= 16
+// (tools/fit_pmecorr.py, max abs error 2.8e-8, 1.0e-7 evaluated in float32). With it the
+// real-space Ewald force needs no exponential: F/r = qq (1/r^3 - beta^3 g(beta^2 r^2)).
+__device__ __forceinline__ float mdx_pmecorr(float w)
+{
+    float p = -3.019193526e-07f;
+    p = fmaf(p, w, 3.398092343e-05f);
+    p = fmaf(p, w, 3.999912512e-04f);
+    p = fmaf(p, w, 1.652836129e-02f);
+    p = fmaf(p, w, -9.232622142e-03f);
+    p = fmaf(p, w, 7.522528031e-01f);
+    float q = 1.872059403e-04f;
+    q = fmaf(q, w, 2.760296177e-03f);
+    q = fmaf(q, w, 2.635980529e-02f);
+    q = fmaf(q, w, 1.603129271e-01f);
+    q = fmaf(q, w, 5.877281614e-01f);
+    q = fmaf(q, w, 1.0f);
+    return p * __builtin_amdgcn_rcpf(q);
+}
+
+// Second-generation kernel: the <= 32 list entries of a work unit are fetched with one coalesced
+// load and broadcast with v_readlane, the j-atoms of entry e+1 are requested before entry e is
+// evaluated, two j-clusters share one 48-lane float atomic, and the force-only variant replaces
+// exp + erfc by the rational Ewald correction above.
+template <bool ENERGY>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_v2(NbArgs A)
+{
+    const int lane = threadIdx.x & 63;
+    const int ti = lane & 7, tj = lane >> 3;
+    const int nwork = A.d->nwork;
+    const int nwaves = gridDim.x * 4;
+    float elj = 0.0f, ecoul = 0.0f;
+    unsigned int npair = 0, nlj = 0;
+    float vxx = 0.0f, vxy = 0.0f, vxz = 0.0f, vyy = 0.0f, vyz = 0.0f, vzz = 0.0f;
+    const float rc2 = A.rc2, beta = A.beta;
+    const float beta2 = beta * beta, beta3 = beta2 * beta;
+    const float nb2l2e = -beta2 * 1.4426950408889634f;
+    // Work units are sorted by descending cost; a static snake deal over the sorted order keeps the
+    // waves balanced (a returning-atomic work queue measured 1.6x slower than this).
+    const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int round = 0; round * nwaves < nwork; round++) {
+        // snake order over the cost-sorted units: even rounds ascend, odd rounds descend
+        const int unit = (round & 1) ? (round + 1) * nwaves - 1 - wave_id : round * nwaves + wave_id;
+        if (unit >= nwork) continue;
+        const NbWork w = A.work[A.order[unit]];
+        const int sci = __builtin_amdgcn_readfirstlane(w.sci);
+        const int e0 = __builtin_amdgcn_readfirstlane(w.cj_start);
+        const int count = __builtin_amdgcn_readfirstlane(w.cj_end) - e0;
+        const float4 S = A.shiftvec[__builtin_amdgcn_readfirstlane(w.shift) & 0xFF];
+        NbEntry myent; myent.cj = 0; myent.mask = 0;
+        if (lane < count) myent = A.cj[e0 + lane];
+        float xi[8], yi[8], zi[8], qi[8], hsi[8], sei[8];
+        float fix[8], fiy[8], fiz[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int ia = (sci * 8 + c) * 8 + ti;
+            const float4 p = A.xq_s[ia];
+            const float2 l = A.lj_s[ia];
+            xi[c] = p.x - S.x; yi[c] = p.y - S.y; zi[c] = p.z - S.z;
+            qi[c] = p.w * MDX_ONE_4PI_EPS0;
+            hsi[c] = l.x; sei[c] = l.y;
+            fix[c] = 0.0f; fiy[c] = 0.0f; fiz[c] = 0.0f;
+        }
+        int cj_n = __builtin_amdgcn_readlane(myent.cj, 0);
+        float4 pj_n = A.xq_s[cj_n * 8 + tj];
+        float2 lj_n = A.lj_s[cj_n * 8 + tj];
+        float hold = 0.0f; int hold_addr = 0;
+        for (int e = 0; e < count; e++) {
+            const int cj = cj_n;
+            const float4 pj = pj_n;
+            const float2 lj = lj_n;
+            const unsigned mk = (unsigned)__builtin_amdgcn_readlane((int)myent.mask, e);
+            if (e + 1 < count) {
+                cj_n = __builtin_amdgcn_readlane(myent.cj, e + 1);
+                pj_n = A.xq_s[cj_n * 8 + tj];
+                lj_n = A.lj_s[cj_n * 8 + tj];
+            }
+            const unsigned imask = mk & 0xFFu;
+            const unsigned slot = mk >> 8;
+            unsigned ex = 0xFFu;
+            if (slot) ex = A.exclmask[(size_t)slot * 64 + lane];
+            float fjx = 0.0f, fjy = 0.0f, fjz = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                if (imask & (1u << c)) {
+                    const float dx = xi[c] - pj.x, dy = yi[c] - pj.y, dz = zi[c] - pj.z;
+                    float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                    const bool within = (r2 < rc2) && ((ex >> c) & 1u);
+                    r2 = fmaxf(r2, 1.0e-12f);
+                    const float rinv = __frsqrt_rn(r2);
+                    const float rinv2 = rinv * rinv;
+                    const float sg = hsi[c] + lj.x;
+                    const float e4 = sei[c] * lj.y;
+                    const float s2 = sg * sg * rinv2;
+                    const float s6 = s2 * s2 * s2;
+                    const float t6 = e4 * s6;
+                    float fs = t6 * fmaf(12.0f, s6, -6.0f);
+                    const float qq = qi[c] * pj.w;
+                    float erfc_br = 0.0f;
+                    if (ENERGY) {
+                        const float br = beta * r2 * rinv;
+                        const float ex2 = __builtin_amdgcn_exp2f(nb2l2e * r2);
+                        erfc_br = ex2 * mdx_erfcx_poly(br);
+                        fs = fmaf(qq * rinv, fmaf(MDX_2_SQRTPI * br, ex2, erfc_br), fs);
+                        fs *= rinv2;
+                    } else {
+                        // (t6 (12 s6 - 6) + qq/r) / r^2 - qq beta^3 g
+                        fs = fmaf(qq, rinv, fs) * rinv2;
+                        fs = fmaf(-qq * beta3, mdx_pmecorr(beta2 * r2), fs);
+                    }
+                    fs = within ? fs : 0.0f;
+                    const float fx = fs * dx, fy = fs * dy, fz = fs * dz;
+                    fix[c] += fx; fiy[c] += fy; fiz[c] += fz;
+                    fjx -= fx; fjy -= fy; fjz -= fz;
+                    if (ENERGY) {
+                        if (within) {
+                            npair++;
+                            if (e4 != 0.0f) nlj++;
+                            const float c2 = sg * sg * (1.0f / rc2);
+                            const float c6 = c2 * c2 * c2;
+                            elj += t6 * (s6 - 1.0f) - e4 * c6 * (c6 - 1.0f);
+                            ecoul += qq * (erfc_br * rinv - A.c_rf_shift);
+                        }
+                        vxx = fmaf(dx, fx, vxx); vxy = fmaf(dx, fy, vxy); vxz = fmaf(dx, fz, vxz);
+                        vyy = fmaf(dy, fy, vyy); vyz = fmaf(dy, fz, vyz); vzz = fmaf(dz, fz, vzz);
+                    }
+                }
+            }
+            fjx = sum8(fjx); fjy = sum8(fjy); fjz = sum8(fjz);
+            const int ja3 = 3 * (cj * 8 + tj);
+            if (((e & 1) == 0) && (e + 1 < count)) {
+                // keep this cluster's components on lanes ti = 0..2 until the next one is ready
+                hold = (ti == 0) ? fjx : ((ti == 1) ? fjy : fjz);
+                hold_addr = ja3 + ti;
+            } else if (e & 1) {
+                const float cur = (ti == 3) ? fjx : ((ti == 4) ? fjy : fjz);
+                const float val = (ti < 3) ? hold : cur;
+                const int addr = (ti < 3) ? hold_addr : ja3 + ti - 3;
+                if (ti < 6) atomicAdd(&A.f_s[addr], val);
+            } else {
+                if (ti < 3) atomicAdd(&A.f_s[ja3 + ti], (ti == 0) ? fjx : ((ti == 1) ? fjy : fjz));
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            float ax = fix[c], ay = fiy[c], az = fiz[c];
+            ax += dpp_row_ror8(ax); ay += dpp_row_ror8(ay); az += dpp_row_ror8(az);
+            ax += __shfl_xor(ax, 16, 64); ay += __shfl_xor(ay, 16, 64); az += __shfl_xor(az, 16, 64);
+            ax += __shfl_xor(ax, 32, 64); ay += __shfl_xor(ay, 32, 64); az += __shfl_xor(az, 32, 64);
+            if (tj < 3) {
+                const float val = (tj == 0) ? ax : ((tj == 1) ? ay : az);
+                atomicAdd(&A.f_s[3 * ((sci * 8 + c) * 8 + ti) + tj], val);
+            }
+        }
+    }
+    if (ENERGY) {
+        elj = wave_sum(elj); ecoul = wave_sum(ecoul);
+        vxx = wave_sum(vxx); vxy = wave_sum(vxy); vxz = wave_sum(vxz);
+        vyy = wave_sum(vyy); vyz = wave_sum(vyz); vzz = wave_sum(vzz);
+        unsigned long long np64 = npair, nl64 = nlj;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { np64 += __shfl_xor(np64, o, 64); nl64 += __shfl_xor(nl64, o, 64); }
+        if (lane == 0) {
+            atomicAdd(&A.dw->npairs_rc, np64);
+            atomicAdd(&A.dw->npairs_lj, nl64);
+            atomicAdd(&A.dw->ener[MDX_E_LJ], (double)elj);
+            atomicAdd(&A.dw->ener[MDX_E_COUL_SR], (double)ecoul);
+            double *v = A.dw->vir;
+            atomicAdd(&v[0], -0.5 * vxx); atomicAdd(&v[1], -0.5 * vxy); atomicAdd(&v[2], -0.5 * vxz);
+            atomicAdd(&v[3], -0.5 * vxy); atomicAdd(&v[4], -0.5 * vyy); atomicAdd(&v[5], -0.5 * vyz);
+            atomicAdd(&v[6], -0.5 * vxz); atomicAdd(&v[7], -0.5 * vyz); atomicAdd(&v[8], -0.5 * vzz);
+        }
+    }
+}
+
 int mdx_launch_nonbonded(mdx_system *s, bool energy)
 {
     NbArgs A;
-    A.d = s->d; A.dw = s->d; A.work = s->work; A.cj = s->cj; A.exclmask = s->exclmask; A.xq_s = s->xq_s; A.lj_s = s->lj_s;
+    A.d = s->d; A.dw = s->d; A.work = s->work; A.order = s->work_order; A.cj = s->cj; A.exclmask = s->exclmask; A.xq_s = s->xq_s; A.lj_s = s->lj_s;
     A.shiftvec = s->shiftvec; A.f_s = s->f_s;
     A.rc2 = s->rc * s->rc; A.beta = s->beta;
     A.c_rf_shift = (float)(erfc((double)s->beta * s->rc) / s->rc);
@@ -181,12 +359,50 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy)
         e0 = (int)s->ev_pool.size() - 2; e1 = e0 + 1;
         MDX_CHECK(s, hipEventRecord(s->ev_pool[e0], s->stream));
     }
-    if (energy) hipLaunchKernelGGL(k_nonbonded<true>, dim3(nblk), dim3(256), 0, s->stream, A);
-    else hipLaunchKernelGGL(k_nonbonded<false>, dim3(nblk), dim3(256), 0, s->stream, A);
+    const int variant = s->nb_variant;
+    if (variant == 1) {
+        if (energy) hipLaunchKernelGGL(k_nonbonded<true>, dim3(nblk), dim3(256), 0, s->stream, A);
+        else hipLaunchKernelGGL(k_nonbonded<false>, dim3(nblk), dim3(256), 0, s->stream, A);
+    } else {
+        if (energy) hipLaunchKernelGGL(k_nonbonded_v2<true>, dim3(nblk), dim3(256), 0, s->stream, A);
+        else hipLaunchKernelGGL(k_nonbonded_v2<false>, dim3(nblk), dim3(256), 0, s->stream, A);
+    }
     MDX_CHECK(s, hipGetLastError());
     if (s->time_nb) {
         MDX_CHECK(s, hipEventRecord(s->ev_pool[e1], s->stream));
         s->ev_nb.push_back(std::make_pair(e0, e1));
     }
     return MDX_OK;
+}
+
+// Diagnostic: time `iters` back-to-back launches of the nonbonded kernel on the current list
+// (forces accumulate garbage into the sorted buffer, which the next step clears).
+extern "C" int mdx_debug_time_nonbonded(mdx_system *s, int energy, int iters, double *avg_ms)
+{
+    (void)hipSetDevice(s->device);
+    hipEvent_t a, b;
+    MDX_CHECK(s, hipEventCreate(&a)); MDX_CHECK(s, hipEventCreate(&b));
+    const bool keep = s->time_nb; s->time_nb = false;
+    (void)hipMemsetAsync((char *)s->d + offsetof(DevState, work_head), 0, sizeof(int) * 8, s->stream);
+    int rc = mdx_launch_nonbonded(s, energy != 0);          // warm
+    MDX_CHECK(s, hipEventRecord(a, s->stream));
+    for (int i = 0; i < iters && rc == MDX_OK; i++) {
+        (void)hipMemsetAsync((char *)s->d + offsetof(DevState, work_head), 0, sizeof(int) * 8, s->stream);
+        rc = mdx_launch_nonbonded(s, energy != 0);
+    }
+    MDX_CHECK(s, hipEventRecord(b, s->stream));
+    MDX_CHECK(s, hipEventSynchronize(b));
+    float ms = 0.0f;
+    MDX_CHECK(s, hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    s->time_nb = keep;
+    if (avg_ms) *avg_ms = ms / (iters > 0 ? iters : 1);
+    return rc;
+}
+
+extern "C" int mdx_debug_set(mdx_system *s, int key, int value)
+{
+    if (key == 1) { s->nb_variant = value; return MDX_OK; }
+    if (key == 2) { s->dbg = value; return MDX_OK; }
+    s->err = "mdx_debug_set: unknown key"; return MDX_ERR_ARG;
 }

@@ -244,6 +244,9 @@ __global__ __launch_bounds__(256) void k_build_list(ListArgs A)
     __shared__ int orig_sh[64];
     __shared__ NbEntry ebuf[EBUF];
     __shared__ int s_nent, s_start, s_w0;
+    __shared__ float4 xj_sh[4][64];      // per wave: the 64 atoms of the candidate j-super-cluster
+    __shared__ int molj_sh[4][64];
+    __shared__ int origj_sh[4][64];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int sci = blockIdx.x;
     const int nsc = A.dro->nsc;
@@ -293,14 +296,20 @@ __global__ __launch_bounds__(256) void k_build_list(ListArgs A)
                         bool okc = bb_dist2(ilo, ihi, A.bb_lo[scj * 8 + tj], A.bb_hi[scj * 8 + tj]) < rl2;
                         if (central && scj == sci) okc = okc && (tj >= ti);
                         const unsigned long long cm = __ballot(okc);
+                        if (!cm) continue;
+                        // one coalesced fetch of the whole j-super-cluster instead of 8 dependent ones
+                        xj_sh[wv][lane] = A.xq_s[scj * 64 + lane];
+                        molj_sh[wv][lane] = A.molid_s[scj * 64 + lane];
+                        origj_sh[wv][lane] = A.perm[scj * 64 + lane];
+                        __builtin_amdgcn_wave_barrier();
                         for (int cjl = 0; cjl < 8; cjl++) {
                             const unsigned im = (unsigned)((cm >> (8 * cjl)) & 0xFFull);
                             if (!im) continue;
                             const int cjg = scj * 8 + cjl;
                             // atom level: lane = (i-atom ti, j-atom tj)
-                            const float4 xj = A.xq_s[cjg * 8 + tj];
-                            const int molj = A.molid_s[cjg * 8 + tj];
-                            const int origj = A.perm[cjg * 8 + tj];
+                            const float4 xj = xj_sh[wv][cjl * 8 + tj];
+                            const int molj = molj_sh[wv][cjl * 8 + tj];
+                            const int origj = origj_sh[wv][cjl * 8 + tj];
                             unsigned newim = 0, exb = 0xFF;
                             for (int ci = 0; ci < 8; ci++) {
                                 if (!(im & (1u << ci))) continue;
@@ -346,8 +355,12 @@ __global__ __launch_bounds__(256) void k_build_list(ListArgs A)
             if (start + nent <= A.cj_cap && w0 + nw <= A.work_cap) {
                 for (int k = threadIdx.x; k < nent; k += 256) A.cj[start + k] = ebuf[k];
                 for (int k = threadIdx.x; k < nw; k += 256) {
-                    NbWork w; w.sci = sci; w.shift = s; w.cj_start = start + k * MDX_NB_CHUNK;
+                    NbWork w; w.sci = sci; w.cj_start = start + k * MDX_NB_CHUNK;
                     w.cj_end = min(start + nent, w.cj_start + MDX_NB_CHUNK);
+                    // cost = number of 8x8 tiles of the unit, kept next to the shift index for the sort
+                    int cost = 0;
+                    for (int q = k * MDX_NB_CHUNK; q < min(nent, (k + 1) * MDX_NB_CHUNK); q++) cost += __popc(ebuf[q].mask & 0xFFu);
+                    w.shift = s | (cost << 8);
                     A.work[w0 + k] = w;
                 }
             } else if (threadIdx.x == 0) atomicOr(&A.d->overflow, (start + nent > A.cj_cap) ? 1 : 2);
@@ -358,14 +371,38 @@ __global__ __launch_bounds__(256) void k_build_list(ListArgs A)
     }
 }
 
+// Order the work units by descending tile count (counting sort on the cost stored next to the
+// shift index). The nonbonded kernel hands unit k, k+W, k+2W, ... to wave k, so every wave gets
+// one unit of each cost tier and the waves finish together.
+__global__ void k_sort_work(const DevState *__restrict__ d, const NbWork *__restrict__ work, int *__restrict__ order, int cap)
+{
+    __shared__ int hist[257];
+    __shared__ int first[257];
+    const int n = min(d->nwork, cap);
+    for (int c = threadIdx.x; c < 257; c += blockDim.x) hist[c] = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += blockDim.x) atomicAdd(&hist[min(256, work[k].shift >> 8)], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int c = 256; c >= 0; c--) { first[c] = run; run += hist[c]; }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        const int pos = atomicAdd(&first[min(256, work[k].shift >> 8)], 1);
+        order[pos] = k;
+    }
+}
+
 // Per step: refresh the sorted coordinates from the state and clear the sorted force buffer.
-__global__ void k_prepare(int npad, const DevState *__restrict__ d, const float4 *__restrict__ x,
+__global__ void k_prepare(int npad, DevState *__restrict__ d, const float4 *__restrict__ x,
                           const int *__restrict__ perm, const int *__restrict__ perm_src,
                           const int *__restrict__ shift_s, float4 *__restrict__ xq_s, float *__restrict__ f_s,
                           int nshift, const int3 *__restrict__ shift_ijk, float4 *__restrict__ shiftvec)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const float *h = d->box.h;
+    if (g < 8) d->work_head[g] = 0;          // work queues of the nonbonded kernel
     if (g < nshift) {
         const int3 s = shift_ijk[g];
         shiftvec[g] = make_float4(s.x * h[0] + s.y * h[3] + s.z * h[6], s.y * h[4] + s.z * h[7], s.z * h[8], 0.0f);
@@ -462,6 +499,7 @@ int mdx_search(mdx_system *s)
     A.exclmask = s->exclmask; A.excl_cap = s->excl_cap; A.rlist = s->rlist;
     const int nblk = s->npad / 64;
     hipLaunchKernelGGL(k_build_list, dim3(nblk), dim3(256), 0, s->stream, A);
+    hipLaunchKernelGGL(k_sort_work, dim3(1), dim3(1024), 0, s->stream, s->d, s->work, s->work_order, s->work_cap);
     MDX_CHECK(s, hipGetLastError());
     s->steps_since_search = 0;
     return MDX_OK;

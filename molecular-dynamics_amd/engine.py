@@ -28,7 +28,8 @@ SYMBOLS = [
     "mdx_set_pcoupl", "mdx_set_dispcorr", "mdx_set_pull", "mdx_set_state", "mdx_set_state_device", "mdx_get_state",
     "mdx_get_step", "mdx_compute_forces", "mdx_get_forces", "mdx_get_energies", "mdx_get_virial", "mdx_step",
     "mdx_synchronize", "mdx_get_list_stats", "mdx_pop_energy_frames", "mdx_pop_pull_records",
-    "mdx_enable_kernel_timing", "mdx_get_kernel_timing",
+    "mdx_enable_kernel_timing", "mdx_get_kernel_timing", "mdx_debug_time_nonbonded", "mdx_debug_set",
+    "mdx_debug_time_stage",
 ]
 
 
@@ -84,6 +85,9 @@ def load_library(path: str | None = None):
     L.mdx_pop_pull_records.restype = ctypes.c_longlong; L.mdx_pop_pull_records.argtypes = [vp, dp, ctypes.c_longlong]
     L.mdx_enable_kernel_timing.argtypes = [vp, c_int]
     L.mdx_get_kernel_timing.argtypes = [vp, dp, llp]
+    L.mdx_debug_time_nonbonded.argtypes = [vp, c_int, c_int, dp]
+    L.mdx_debug_set.argtypes = [vp, c_int, c_int]
+    L.mdx_debug_time_stage.argtypes = [vp, c_int, c_int, dp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is c_int and name not in ("mdx_version",):
@@ -300,6 +304,19 @@ class Engine:
 
     def enable_kernel_timing(self, on=True):
         self._call("mdx_enable_kernel_timing", 1 if on else 0)
+
+    def debug_time_nonbonded(self, energy=False, iters=50):
+        ms = ctypes.c_double(0)
+        self._call("mdx_debug_time_nonbonded", 1 if energy else 0, int(iters), ctypes.byref(ms))
+        return ms.value
+
+    def debug_time_stage(self, stage, iters=20):
+        ms = ctypes.c_double(0)
+        self._call("mdx_debug_time_stage", int(stage), int(iters), ctypes.byref(ms))
+        return ms.value
+
+    def debug_set(self, key, value):
+        self._call("mdx_debug_set", int(key), int(value))
 
     def kernel_timing(self):
         ms = ctypes.c_double(0); nl = ctypes.c_longlong(0)
