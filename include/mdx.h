@@ -140,6 +140,34 @@ int mdx_set_state(mdx_system *sys, const float *x, const float *v, const float *
 int mdx_set_state_device(mdx_system *sys, const void *x_device, const void *v_device, const float *box9);
 int mdx_get_state(mdx_system *sys, float *x, float *v, float *box9);
 long long mdx_get_step(const mdx_system *sys);
+/* Continue from a checkpoint: the step counter drives output times, coupling cadence and the
+ * counter-based random streams (`gmx mdrun -cpi`,
+ * /root/reference/scripts/run_smd_with_recovery.py:149-156). */
+int mdx_set_step(mdx_system *sys, long long step);
+/* `gen_vel = yes`, `gen_temp`, `gen_seed` (/root/reference/mdp/nvt_complex.mdp:39-41):
+ * Maxwell-Boltzmann velocities, centre-of-mass motion removed, scaled to exactly `temperature`
+ * over 3N degrees of freedom. */
+int mdx_generate_velocities(mdx_system *sys, double temperature, unsigned long long seed);
+/* `continuation = no` (/root/reference/mdp/nvt_complex.mdp:13): project the start coordinates
+ * onto the constraints and remove the velocity components along them. */
+int mdx_constrain_start(mdx_system *sys);
+/* `integrator = steep`, `emtol`, `emstep`, `nsteps` (/root/reference/mdp/em_complex.mdp:3-6):
+ * steepest descent with the force kernels of the MD path; step size grows by 1.2 on an accepted
+ * move and halves on a rejected one. result6: steps done, status (1 converged to emtol, 0 step
+ * limit, 2 step size underflow), final Epot, final Fmax, first Epot, first Fmax. `progress` may
+ * be NULL. */
+int mdx_minimize(mdx_system *sys, long long nsteps, double emtol, double emstep, double *result6,
+                 void (*progress)(long long step, double epot, double fmax, double stepsize));
+/* Trajectory output cadence (`nstxout`, `nstvout`, `nstxout-compressed`,
+ * /root/reference/mdp/production.mdp:7-12): a ring of pinned host slots. mdx_capture_frame
+ * enqueues the copy of the current x (and v) and box behind the steps already enqueued and
+ * returns at once; mdx_frame_wait blocks until that copy has landed and may be called from a
+ * writer thread while the stepping thread keeps enqueuing. Pointers stay valid until the slot
+ * is captured into again. */
+int mdx_frame_ring(mdx_system *sys, int nslots);
+int mdx_capture_frame(mdx_system *sys, int slot, int want_v);
+int mdx_frame_wait(mdx_system *sys, int slot, const float **x, const float **v, double *box9,
+                   long long *step);
 
 /* ---- compute */
 /* Single-point forces and energies of the selected terms at the current positions (rebuilds

@@ -104,6 +104,7 @@ extern "C" void mdx_destroy(mdx_system *s)
     (void)hipSetDevice(s->device);
     (void)hipDeviceSynchronize();
     mdx_pme_free(s);
+    mdx_frames_free(s);
     void *ptrs[] = { s->x, s->xp, s->v, s->f, s->f_pme, s->lj, s->molid, s->tcgrp, s->excl_start, s->excl_list, s->excl_pairs, s->xq_s, s->lj_s,
                      s->f_s, s->perm, s->perm_src, s->shift_s, s->molid_s, s->sorted_of, s->bb_lo, s->bb_hi, s->sbb_lo, s->sbb_hi,
                      s->col_count, s->col_astart, s->col_scstart, s->col_atoms, s->atom_col, s->atom_slot, s->wrapped, s->cj, s->work, s->work_order,

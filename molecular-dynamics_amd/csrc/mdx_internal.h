@@ -163,6 +163,7 @@ struct mdx_system {
     // timing of the dominant kernel (HIP events on this stream)
     bool time_nb = false; std::vector<hipEvent_t> ev_pool; std::vector<std::pair<int, int>> ev_nb;
     double nb_ms_total = 0; long long nb_launches = 0;
+    void *frame_ring = nullptr;   // pinned trajectory-frame slots (runctl.hip)
 };
 
 #define MDX_CHECK(sys, call)                                                                         \
@@ -185,6 +186,8 @@ int mdx_launch_pme(mdx_system *s, bool energy);
 int mdx_launch_bonded(mdx_system *s, bool energy, unsigned flags);
 int mdx_launch_pull(mdx_system *s, bool log_now, bool energy);
 int mdx_launch_update(mdx_system *s, bool do_tc, bool do_pr, bool virial);
+int mdx_launch_constrain(mdx_system *s, float inv_dt, bool virial, int lincs_iter);
+void mdx_frames_free(mdx_system *s);
 int mdx_launch_ke(mdx_system *s, bool old_slot, bool tensor);
 int mdx_launch_clear(mdx_system *s, bool energies, bool ekin_new, bool ekin_old);
 int mdx_launch_tcouple(mdx_system *s);

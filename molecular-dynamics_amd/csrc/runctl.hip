@@ -1,0 +1,298 @@
+// Run control around the step loop: start-up (velocity generation, constraining the start
+// configuration), continuation (step counter), steepest-descent minimisation and asynchronous
+// trajectory-frame capture.
+// Replaces what `gen_vel/gen_temp/gen_seed` (/root/reference/mdp/nvt_complex.mdp:39-41),
+// `continuation = no` (nvt_complex.mdp:13), `integrator = steep`, `emtol`, `emstep`
+// (/root/reference/mdp/em_complex.mdp:3-6) and the output cadence keys `nstxout`,
+// `nstvout`, `nstxout-compressed` (/root/reference/mdp/production.mdp:7-12) switch on in gmx mdrun.
+#include "mdx_internal.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#define ARG_CHECK(sys, cond, msg)                                   \
+    do {                                                            \
+        if (!(cond)) { (sys)->err = (msg); return MDX_ERR_ARG; }    \
+    } while (0)
+
+extern "C" int mdx_set_step(mdx_system *s, long long step)
+{
+    ARG_CHECK(s, step >= 0, "mdx_set_step: step must be >= 0");
+    s->step = step;
+    s->steps_since_search = 1 << 30;
+    s->first_step = true;
+    return MDX_OK;
+}
+
+// ---------------------------------------------------------------- velocity generation
+// Maxwell-Boltzmann: each component N(0, kT/m), one counter-based stream per atom.
+__global__ __launch_bounds__(256) void k_gen_vel(int n, float4 *__restrict__ v, double kT, unsigned long long seed)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 vi = v[i];
+    if (vi.w > 0.0f) {
+        RngStream rng(seed, 0x9e0000ull, (uint64_t)i);
+        const double sd = sqrt(kT * (double)vi.w);
+        vi.x = (float)(sd * rng.gauss()); vi.y = (float)(sd * rng.gauss()); vi.z = (float)(sd * rng.gauss());
+    } else {
+        vi.x = vi.y = vi.z = 0.0f;
+    }
+    v[i] = vi;
+}
+
+__global__ __launch_bounds__(256) void k_scale_vel_to(int n, float4 *__restrict__ v, const DevState *__restrict__ d, double ekin_target)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double ek = 0.0;
+    for (int g = 0; g < MDX_MAX_TC; g++) ek += d->ekinh[g];
+    const float sc = ek > 0.0 ? (float)sqrt(ekin_target / ek) : 1.0f;
+    float4 vi = v[i];
+    vi.x *= sc; vi.y *= sc; vi.z *= sc;
+    v[i] = vi;
+}
+
+extern "C" int mdx_generate_velocities(mdx_system *s, double temperature, unsigned long long seed)
+{
+    (void)hipSetDevice(s->device);
+    ARG_CHECK(s, temperature >= 0.0, "mdx_generate_velocities: negative temperature");
+    const int n = s->n, nb = (n + 255) / 256;
+    hipLaunchKernelGGL(k_gen_vel, dim3(nb), dim3(256), 0, s->stream, n, s->v, MDX_BOLTZ * temperature, seed);
+    int rc;
+    if ((rc = mdx_launch_comm(s))) return rc;
+    // scale to exactly `temperature` counting 3N degrees of freedom, as the generator does before
+    // any constraint is applied
+    if ((rc = mdx_launch_clear(s, false, true, false))) return rc;
+    if ((rc = mdx_launch_ke(s, false, false))) return rc;
+    hipLaunchKernelGGL(k_scale_vel_to, dim3(nb), dim3(256), 0, s->stream, n, s->v, s->d, 0.5 * 3.0 * n * MDX_BOLTZ * temperature);
+    MDX_CHECK(s, hipGetLastError());
+    s->first_step = true;
+    MDX_CHECK(s, hipStreamSynchronize(s->stream));
+    return MDX_OK;
+}
+
+// ---------------------------------------------------------------- constraining the start
+__global__ __launch_bounds__(256) void k_copy_pos(int n, const float4 *__restrict__ x, float4 *__restrict__ xp, const float4 *__restrict__ v, float back_dt)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 p = x[i];
+    if (back_dt != 0.0f) { const float4 w = v[i]; p.x -= back_dt * w.x; p.y -= back_dt * w.y; p.z -= back_dt * w.z; }
+    xp[i] = p;
+}
+
+extern "C" int mdx_constrain_start(mdx_system *s)
+{
+    (void)hipSetDevice(s->device);
+    if (s->nsettle == 0 && s->ncomp == 0) return MDX_OK;
+    const int n = s->n, nb = (n + 255) / 256;
+    int rc;
+    // positions: project x(0) onto the constraint manifold, reference directions from x(0) itself
+    hipLaunchKernelGGL(k_copy_pos, dim3(nb), dim3(256), 0, s->stream, n, s->x, s->xp, s->v, 0.0f);
+    if ((rc = mdx_launch_constrain(s, 0.0f, false, std::max(s->lincs_iter, 4)))) return rc;
+    { float4 *t = s->x; s->x = s->xp; s->xp = t; }
+    // velocities: constrain x(-dt) = x(0) - dt v against x(0); the displacement it takes, divided
+    // by -dt, removes the velocity components along the constraints
+    hipLaunchKernelGGL(k_copy_pos, dim3(nb), dim3(256), 0, s->stream, n, s->x, s->xp, s->v, s->dt);
+    if ((rc = mdx_launch_constrain(s, -1.0f / s->dt, false, std::max(s->lincs_iter, 4)))) return rc;
+    MDX_CHECK(s, hipGetLastError());
+    s->steps_since_search = 1 << 30; s->first_step = true; s->forces_current = false;
+    MDX_CHECK(s, hipStreamSynchronize(s->stream));
+    return MDX_OK;
+}
+
+// ---------------------------------------------------------------- steepest descent
+__device__ inline void atomic_max_pos_float(float *addr, float val)
+{
+    atomicMax((int *)addr, __float_as_int(val));      // valid for non-negative floats
+}
+
+__global__ __launch_bounds__(256) void k_fmax(int n, const float *__restrict__ f, const float *__restrict__ f_pme, const float *__restrict__ f_s,
+                                              const int *__restrict__ sorted_of, const float4 *__restrict__ v, float *__restrict__ out2)
+{
+    __shared__ float red[4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float f2 = 0.0f;
+    if (i < n && v[i].w > 0.0f) {
+        const int g = sorted_of[i];
+        const float a = f[3 * i] + f_pme[3 * i] + f_s[3 * g], b = f[3 * i + 1] + f_pme[3 * i + 1] + f_s[3 * g + 1],
+                    c = f[3 * i + 2] + f_pme[3 * i + 2] + f_s[3 * g + 2];
+        f2 = a * a + b * b + c * c;
+    }
+    for (int o = 32; o > 0; o >>= 1) f2 = fmaxf(f2, __shfl_xor(f2, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = f2;
+    __syncthreads();
+    if (threadIdx.x == 0) atomic_max_pos_float(out2, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
+
+__global__ __launch_bounds__(256) void k_sd_move(int n, const float4 *__restrict__ x, float4 *__restrict__ xp, const float *__restrict__ f,
+                                                 const float *__restrict__ f_pme, const float *__restrict__ f_s,
+                                                 const int *__restrict__ sorted_of, const float4 *__restrict__ v, float scale)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 p = x[i];
+    if (v[i].w > 0.0f) {
+        const int g = sorted_of[i];
+        p.x += scale * (f[3 * i] + f_pme[3 * i] + f_s[3 * g]);
+        p.y += scale * (f[3 * i + 1] + f_pme[3 * i + 1] + f_s[3 * g + 1]);
+        p.z += scale * (f[3 * i + 2] + f_pme[3 * i + 2] + f_s[3 * g + 2]);
+    }
+    xp[i] = p;
+}
+
+// result6: [0] steps done, [1] converged (1) / step limit (0) / step size underflow (2),
+// [2] final potential energy, [3] final max force, [4] first potential energy, [5] first max force.
+// Each trial costs one full force evaluation including a new pair list (`nstlist = 1` in em.mdp).
+extern "C" int mdx_minimize(mdx_system *s, long long nsteps, double emtol, double emstep, double *result6,
+                            void (*progress)(long long step, double epot, double fmax, double stepsize))
+{
+    (void)hipSetDevice(s->device);
+    ARG_CHECK(s, nsteps >= 0 && emstep > 0.0, "mdx_minimize: nsteps >= 0 and emstep > 0 required");
+    const int n = s->n, nb = (n + 255) / 256;
+    const unsigned terms = MDX_F_ALL & ~MDX_F_PULL;
+    float *d_fmax = nullptr;
+    MDX_CHECK(s, hipMalloc((void **)&d_fmax, sizeof(float)));
+    auto evaluate = [&](double *epot, double *fmax) -> int {
+        int rc = mdx_compute_forces(s, terms);
+        if (rc) return rc;
+        MDX_CHECK(s, hipMemsetAsync(d_fmax, 0, sizeof(float), s->stream));
+        hipLaunchKernelGGL(k_fmax, dim3(nb), dim3(256), 0, s->stream, n, s->f, s->f_pme, s->f_s, s->sorted_of, s->v, d_fmax);
+        float f2 = 0.0f;
+        MDX_CHECK(s, hipMemcpyAsync(&f2, d_fmax, sizeof(float), hipMemcpyDeviceToHost, s->stream));
+        MDX_CHECK(s, hipStreamSynchronize(s->stream));
+        *epot = s->h->ener[MDX_E_POT];
+        *fmax = std::sqrt((double)f2);
+        return MDX_OK;
+    };
+    // start from a constrained geometry
+    int rc = MDX_OK;
+    if (s->nsettle > 0 || s->ncomp > 0) {
+        hipLaunchKernelGGL(k_copy_pos, dim3(nb), dim3(256), 0, s->stream, n, s->x, s->xp, s->v, 0.0f);
+        rc = mdx_launch_constrain(s, 0.0f, false, std::max(s->lincs_iter, 4));
+        if (rc == MDX_OK) { float4 *t = s->x; s->x = s->xp; s->xp = t; }
+    }
+    double epot = 0, fmax = 0, step = emstep;
+    if (rc == MDX_OK) rc = evaluate(&epot, &fmax);
+    const double e0 = epot, f0 = fmax;
+    long long it = 0;
+    int status = 0;
+    while (rc == MDX_OK) {
+        if (progress) progress(it, epot, fmax, step);
+        if (!std::isfinite(epot) || !std::isfinite(fmax)) { s->err = "mdx_minimize: non-finite energy or force"; rc = MDX_ERR_STATE; break; }
+        if (fmax < emtol) { status = 1; break; }
+        if (it >= nsteps) { status = 0; break; }
+        if (step < 1e-7 * emstep || fmax == 0.0) { status = 2; break; }
+        // trial move along the force, largest displacement = step
+        hipLaunchKernelGGL(k_sd_move, dim3(nb), dim3(256), 0, s->stream, n, s->x, s->xp, s->f, s->f_pme, s->f_s, s->sorted_of, s->v,
+                           (float)(step / fmax));
+        if ((rc = mdx_launch_constrain(s, 0.0f, false, std::max(s->lincs_iter, 2)))) break;
+        { float4 *t = s->x; s->x = s->xp; s->xp = t; }      // trial becomes current, old kept in xp
+        double e_try = 0, f_try = 0;
+        if ((rc = evaluate(&e_try, &f_try))) break;
+        it++;
+        if (std::isfinite(e_try) && e_try < epot) {
+            epot = e_try; fmax = f_try; step *= 1.2;
+        } else {
+            { float4 *t = s->x; s->x = s->xp; s->xp = t; }  // reject: restore
+            step *= 0.5;
+            double e_back = 0, f_back = 0;
+            if ((rc = evaluate(&e_back, &f_back))) break;   // forces of the kept geometry are needed again
+            epot = e_back; fmax = f_back;
+        }
+    }
+    (void)hipFree(d_fmax);
+    if (result6) { result6[0] = (double)it; result6[1] = status; result6[2] = epot; result6[3] = fmax; result6[4] = e0; result6[5] = f0; }
+    s->steps_since_search = 1 << 30; s->first_step = true;
+    return rc;
+}
+
+// ---------------------------------------------------------------- trajectory frames
+// A ring of pinned host slots; a capture enqueues an unpack kernel and device-to-host copies on
+// the main stream followed by an event, so the step loop keeps running while a writer thread
+// waits for the event and encodes the frame.
+__global__ __launch_bounds__(256) void k_unpack3(int n, const float4 *__restrict__ a, float *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = a[i];
+    out[3 * i] = p.x; out[3 * i + 1] = p.y; out[3 * i + 2] = p.z;
+}
+
+struct FrameSlot { float *x = nullptr, *v = nullptr; double *box = nullptr; hipEvent_t ev = nullptr; long long step = -1; int has_v = 0; };
+struct FrameRing { std::vector<FrameSlot> slots; float *d_stage = nullptr; };
+static FrameRing *ring_of(mdx_system *s) { return (FrameRing *)s->frame_ring; }
+
+void mdx_frames_free(mdx_system *s)
+{
+    FrameRing *r = ring_of(s);
+    if (!r) return;
+    for (FrameSlot &f : r->slots) {
+        if (f.x) (void)hipHostFree(f.x);
+        if (f.v) (void)hipHostFree(f.v);
+        if (f.box) (void)hipHostFree(f.box);
+        if (f.ev) (void)hipEventDestroy(f.ev);
+    }
+    if (r->d_stage) (void)hipFree(r->d_stage);
+    delete r;
+    s->frame_ring = nullptr;
+}
+
+extern "C" int mdx_frame_ring(mdx_system *s, int nslots)
+{
+    (void)hipSetDevice(s->device);
+    ARG_CHECK(s, nslots >= 1 && nslots <= 64, "mdx_frame_ring: 1..64 slots");
+    mdx_frames_free(s);
+    FrameRing *r = new FrameRing();
+    s->frame_ring = r;
+    r->slots.resize(nslots);
+    const size_t bytes = sizeof(float) * 3 * (size_t)s->n;
+    for (FrameSlot &f : r->slots) {
+        MDX_CHECK(s, hipHostMalloc((void **)&f.x, bytes, hipHostMallocDefault));
+        MDX_CHECK(s, hipHostMalloc((void **)&f.v, bytes, hipHostMallocDefault));
+        MDX_CHECK(s, hipHostMalloc((void **)&f.box, sizeof(double) * 9, hipHostMallocDefault));
+        MDX_CHECK(s, hipEventCreateWithFlags(&f.ev, hipEventDisableTiming));
+    }
+    // one staging buffer per slot so that consecutive captures do not wait for each other
+    MDX_CHECK(s, hipMalloc((void **)&r->d_stage, 2 * bytes * nslots));
+    return MDX_OK;
+}
+
+extern "C" int mdx_capture_frame(mdx_system *s, int slot, int want_v)
+{
+    (void)hipSetDevice(s->device);
+    FrameRing *r = ring_of(s);
+    ARG_CHECK(s, r && slot >= 0 && slot < (int)r->slots.size(), "mdx_capture_frame: call mdx_frame_ring first / bad slot");
+    FrameSlot &f = r->slots[slot];
+    const int n = s->n, nb = (n + 255) / 256;
+    const size_t cnt = 3 * (size_t)n;
+    float *dx = r->d_stage + 2 * cnt * slot, *dv = dx + cnt;
+    hipLaunchKernelGGL(k_unpack3, dim3(nb), dim3(256), 0, s->stream, n, s->x, dx);
+    MDX_CHECK(s, hipMemcpyAsync(f.x, dx, sizeof(float) * cnt, hipMemcpyDeviceToHost, s->stream));
+    if (want_v) {
+        hipLaunchKernelGGL(k_unpack3, dim3(nb), dim3(256), 0, s->stream, n, s->v, dv);
+        MDX_CHECK(s, hipMemcpyAsync(f.v, dv, sizeof(float) * cnt, hipMemcpyDeviceToHost, s->stream));
+    }
+    MDX_CHECK(s, hipMemcpyAsync(f.box, s->d->boxd, sizeof(double) * 9, hipMemcpyDeviceToHost, s->stream));
+    MDX_CHECK(s, hipEventRecord(f.ev, s->stream));
+    f.step = s->step; f.has_v = want_v ? 1 : 0;
+    return MDX_OK;
+}
+
+// Blocks until the capture into `slot` has landed; the pointers stay valid until the slot is
+// captured into again. May be called from another thread than the one that steps.
+extern "C" int mdx_frame_wait(mdx_system *s, int slot, const float **x, const float **v, double *box9, long long *step)
+{
+    FrameRing *r = ring_of(s);
+    ARG_CHECK(s, r && slot >= 0 && slot < (int)r->slots.size(), "mdx_frame_wait: bad slot");
+    FrameSlot &f = r->slots[slot];
+    ARG_CHECK(s, f.step >= 0, "mdx_frame_wait: nothing captured in this slot");
+    (void)hipSetDevice(s->device);
+    if (hipEventSynchronize(f.ev) != hipSuccess) { return MDX_ERR_HIP; }
+    if (x) *x = f.x;
+    if (v) *v = f.has_v ? f.v : nullptr;
+    if (box9) memcpy(box9, f.box, sizeof(double) * 9);
+    if (step) *step = f.step;
+    return MDX_OK;
+}

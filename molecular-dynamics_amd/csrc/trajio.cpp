@@ -1,0 +1,473 @@
+// Trajectory file codecs on the host: compressed `.xtc` frames and full-precision `.trr` frames,
+// both XDR (big-endian) streams.
+// Written for the output cadence the pipeline's .mdp files ask for: `nstxout-compressed`
+// (/root/reference/mdp/production.mdp:12, npt_complex.mdp:17, pull_short.mdp:8) and
+// `nstxout/nstvout` (/root/reference/mdp/nvt_complex.mdp:8-9, production.mdp:7); the files are
+// what `gmx rms`, `gmx trjconv` and gmx_MMPBSA read afterwards
+// (/root/reference/Snakefile:348,1054-1055).
+//
+// The .xtc coordinate block follows the published xtc3 scheme: coordinates are multiplied by the
+// precision and rounded to integers; each atom is sent either as a "large" triple relative to the
+// frame minimum (mixed-radix packed into the fewest bits that hold the frame's extent) or, for
+// runs of up to eight atoms that lie close to their predecessor (water molecules), as "small"
+// triples relative to the previous atom, packed with a radix from a table of ~2^(k/3) sizes that
+// adapts up or down by one entry per run. The first two atoms of a run are interchanged so that
+// a water's oxygen-hydrogen differences stay small.
+//
+// This library has no GPU code: it is built with the host compiler and is usable on its own.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+#include <math.h>
+#include <vector>
+
+extern "C" {
+
+enum { TRJ_OK = 0, TRJ_ERR_IO = -1, TRJ_ERR_RANGE = -2, TRJ_ERR_FORMAT = -3, TRJ_EOF = 1 };
+
+static const int kMagic[] = {
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 10, 12, 16, 20, 25, 32, 40, 50, 64, 80, 101, 128, 161, 203, 256, 322, 406, 512, 645, 812, 1024,
+    1290, 1625, 2048, 2580, 3250, 4096, 5060, 6501, 8192, 10321, 13003, 16384, 20642, 26007, 32768, 41285, 52015, 65536, 82570,
+    104031, 131072, 165140, 208063, 262144, 330280, 416127, 524287, 660561, 832255, 1048576, 1321122, 1664510, 2097152, 2642245,
+    3329021, 4194304, 5284491, 6658042, 8388607, 10568983, 13316085, 16777216
+};
+static const int kFirstIdx = 9;
+static const int kLastIdx = (int)(sizeof(kMagic) / sizeof(kMagic[0]));
+static const float kMaxAbs = (float)(INT_MAX - 2);
+
+// ---------------------------------------------------------------- bit stream (MSB first)
+struct BitWriter {
+    std::vector<unsigned char> buf;
+    unsigned int acc = 0;
+    int nacc = 0;
+    void put(int nbits, unsigned int v)
+    {
+        while (nbits > 0) {
+            const int take = nbits > 8 ? 8 : nbits;
+            const unsigned int chunk = (v >> (nbits - take)) & ((1u << take) - 1u);
+            acc = (acc << take) | chunk;
+            nacc += take;
+            nbits -= take;
+            while (nacc >= 8) { buf.push_back((unsigned char)((acc >> (nacc - 8)) & 0xFFu)); nacc -= 8; }
+            acc &= (1u << nacc) - 1u;
+        }
+    }
+    size_t finish()
+    {
+        if (nacc > 0) { buf.push_back((unsigned char)((acc << (8 - nacc)) & 0xFFu)); nacc = 0; acc = 0; }
+        return buf.size();
+    }
+};
+
+struct BitReader {
+    const unsigned char *p; size_t n, pos = 0; unsigned int acc = 0; int nacc = 0; bool bad = false;
+    BitReader(const unsigned char *d, size_t len) : p(d), n(len) {}
+    unsigned int get(int nbits)
+    {
+        unsigned int out = 0;
+        while (nbits > 0) {
+            if (nacc == 0) { if (pos >= n) { bad = true; return 0; } acc = p[pos++]; nacc = 8; }
+            const int take = nbits < nacc ? nbits : nacc;
+            out = (out << take) | ((acc >> (nacc - take)) & ((1u << take) - 1u));
+            nacc -= take; nbits -= take;
+        }
+        return out;
+    }
+};
+
+static int bits_of(unsigned int size)
+{
+    unsigned int num = 1; int nbits = 0;
+    while (size >= num && nbits < 32) { nbits++; num <<= 1; }
+    return nbits;
+}
+
+// bits needed for a mixed-radix number with the given radices
+static int bits_of_product(const unsigned int sizes[3])
+{
+    unsigned __int128 prod = 1;
+    for (int i = 0; i < 3; i++) prod *= sizes[i];
+    // value of the highest byte decides the bits above the whole bytes
+    int nbytes = 0; unsigned __int128 t = prod;
+    unsigned int top = 0;
+    do { top = (unsigned int)(t & 0xFF); t >>= 8; nbytes++; } while (t != 0);
+    int nbits = 0; unsigned int num = 1;
+    while (top >= num) { nbits++; num *= 2; }
+    return nbits + (nbytes - 1) * 8;
+}
+
+// three numbers, radices sizes[1], sizes[2]: value = (n0*s1 + n1)*s2 + n2, sent low byte first
+static void put_triple(BitWriter &w, int nbits, const unsigned int sizes[3], const unsigned int nums[3])
+{
+    unsigned __int128 v = nums[0];
+    v = v * sizes[1] + nums[1];
+    v = v * sizes[2] + nums[2];
+    unsigned char bytes[16]; int nbytes = 0;
+    do { bytes[nbytes++] = (unsigned char)(v & 0xFF); v >>= 8; } while (v != 0);
+    if (nbits >= nbytes * 8) {
+        for (int i = 0; i < nbytes; i++) w.put(8, bytes[i]);
+        w.put(nbits - nbytes * 8, 0);
+    } else {
+        int i = 0;
+        for (; i < nbytes - 1; i++) w.put(8, bytes[i]);
+        w.put(nbits - (nbytes - 1) * 8, bytes[i]);
+    }
+}
+
+static void get_triple(BitReader &r, int nbits, const unsigned int sizes[3], int out[3])
+{
+    unsigned __int128 v = 0; int shift = 0;
+    while (nbits > 8) { v |= (unsigned __int128)r.get(8) << shift; shift += 8; nbits -= 8; }
+    if (nbits > 0) v |= (unsigned __int128)r.get(nbits) << shift;
+    out[2] = (int)(v % sizes[2]); v /= sizes[2];
+    out[1] = (int)(v % sizes[1]); v /= sizes[1];
+    out[0] = (int)v;
+}
+
+// ---------------------------------------------------------------- XDR primitives
+static void xdr_put_u32(std::vector<unsigned char> &o, uint32_t v)
+{
+    o.push_back((unsigned char)(v >> 24)); o.push_back((unsigned char)(v >> 16)); o.push_back((unsigned char)(v >> 8)); o.push_back((unsigned char)v);
+}
+static void xdr_put_f32(std::vector<unsigned char> &o, float f) { uint32_t u; memcpy(&u, &f, 4); xdr_put_u32(o, u); }
+static uint32_t be32(const unsigned char *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+static float bef32(const unsigned char *p) { uint32_t u = be32(p); float f; memcpy(&f, &u, 4); return f; }
+
+// ---------------------------------------------------------------- xtc coordinate block
+// Appends `natoms` (int), and the raw or compressed coordinates to `o`.
+static int xtc_encode_coords(std::vector<unsigned char> &o, int natoms, const float *x, float precision)
+{
+    xdr_put_u32(o, (uint32_t)natoms);
+    if (natoms <= 9) {
+        for (int i = 0; i < 3 * natoms; i++) xdr_put_f32(o, x[i]);
+        return TRJ_OK;
+    }
+    if (precision <= 0) precision = 1000.0f;
+    xdr_put_f32(o, precision);
+    std::vector<int> ip(3 * (size_t)natoms + 3);
+    int minint[3] = { INT_MAX, INT_MAX, INT_MAX }, maxint[3] = { INT_MIN, INT_MIN, INT_MIN };
+    int mindiff = INT_MAX, old[3] = { 0, 0, 0 };
+    for (int i = 0; i < natoms; i++) {
+        int l[3];
+        for (int d = 0; d < 3; d++) {
+            const float lf = x[3 * i + d] * precision;
+            if (!(fabsf(lf) <= kMaxAbs)) return TRJ_ERR_RANGE;       // also catches NaN
+            l[d] = (int)(lf >= 0 ? lf + 0.5f : lf - 0.5f);
+            if (l[d] < minint[d]) minint[d] = l[d];
+            if (l[d] > maxint[d]) maxint[d] = l[d];
+            ip[3 * (size_t)i + d] = l[d];
+        }
+        const long long diff = llabs((long long)old[0] - l[0]) + llabs((long long)old[1] - l[1]) + llabs((long long)old[2] - l[2]);
+        if (i > 0 && diff < mindiff) mindiff = (int)diff;
+        old[0] = l[0]; old[1] = l[1]; old[2] = l[2];
+    }
+    for (int d = 0; d < 3; d++) xdr_put_u32(o, (uint32_t)minint[d]);
+    for (int d = 0; d < 3; d++) xdr_put_u32(o, (uint32_t)maxint[d]);
+    for (int d = 0; d < 3; d++) if ((float)maxint[d] - (float)minint[d] >= kMaxAbs) return TRJ_ERR_RANGE;
+    unsigned int sizeint[3], bitsizeint[3] = { 0, 0, 0 };
+    for (int d = 0; d < 3; d++) sizeint[d] = (unsigned int)(maxint[d] - minint[d] + 1);
+    int bitsize;
+    if ((sizeint[0] | sizeint[1] | sizeint[2]) > 0xffffff) {
+        for (int d = 0; d < 3; d++) bitsizeint[d] = bits_of(sizeint[d]);
+        bitsize = 0;
+    } else {
+        bitsize = bits_of_product(sizeint);
+    }
+    int smallidx = kFirstIdx;
+    while (smallidx < kLastIdx && kMagic[smallidx] < mindiff) smallidx++;
+    xdr_put_u32(o, (uint32_t)smallidx);
+    const int maxidx = (kLastIdx < smallidx + 8) ? kLastIdx : smallidx + 8;
+    const int minidx = maxidx - 8;
+    int smaller = kMagic[(kFirstIdx > smallidx - 1) ? kFirstIdx : smallidx - 1] / 2;
+    int smallnum = kMagic[smallidx] / 2;
+    unsigned int sizesmall[3] = { (unsigned)kMagic[smallidx], (unsigned)kMagic[smallidx], (unsigned)kMagic[smallidx] };
+    const int larger = kMagic[maxidx < kLastIdx ? maxidx : kLastIdx - 1] / 2;
+    BitWriter w;
+    w.buf.reserve((size_t)natoms * 5);
+    int prev[3] = { 0, 0, 0 };
+    int prevrun = -1;
+    int i = 0;
+    int *c = ip.data();
+    unsigned int tmp[30];
+    while (i < natoms) {
+        bool is_small = false;
+        int is_smaller;
+        if (smallidx < maxidx && i >= 1 && abs(c[0] - prev[0]) < larger && abs(c[1] - prev[1]) < larger && abs(c[2] - prev[2]) < larger)
+            is_smaller = 1;
+        else if (smallidx > minidx)
+            is_smaller = -1;
+        else
+            is_smaller = 0;
+        if (i + 1 < natoms) {
+            if (abs(c[0] - c[3]) < smallnum && abs(c[1] - c[4]) < smallnum && abs(c[2] - c[5]) < smallnum) {
+                // interchange the first with the second atom of the run
+                for (int d = 0; d < 3; d++) { const int t = c[d]; c[d] = c[3 + d]; c[3 + d] = t; }
+                is_small = true;
+            }
+        }
+        unsigned int big[3] = { (unsigned)(c[0] - minint[0]), (unsigned)(c[1] - minint[1]), (unsigned)(c[2] - minint[2]) };
+        if (bitsize == 0) { w.put(bitsizeint[0], big[0]); w.put(bitsizeint[1], big[1]); w.put(bitsizeint[2], big[2]); }
+        else put_triple(w, bitsize, sizeint, big);
+        prev[0] = c[0]; prev[1] = c[1]; prev[2] = c[2];
+        c += 3; i++;
+        int run = 0;
+        if (!is_small && is_smaller == -1) is_smaller = 0;
+        while (is_small && run < 8 * 3) {
+            if (is_smaller == -1) {
+                const long long dx = c[0] - prev[0], dy = c[1] - prev[1], dz = c[2] - prev[2];
+                if (dx * dx + dy * dy + dz * dz >= (long long)smaller * smaller) is_smaller = 0;
+            }
+            tmp[run++] = (unsigned)(c[0] - prev[0] + smallnum);
+            tmp[run++] = (unsigned)(c[1] - prev[1] + smallnum);
+            tmp[run++] = (unsigned)(c[2] - prev[2] + smallnum);
+            prev[0] = c[0]; prev[1] = c[1]; prev[2] = c[2];
+            i++; c += 3;
+            is_small = false;
+            if (i < natoms && abs(c[0] - prev[0]) < smallnum && abs(c[1] - prev[1]) < smallnum && abs(c[2] - prev[2]) < smallnum) is_small = true;
+        }
+        if (run != prevrun || is_smaller != 0) {
+            prevrun = run;
+            w.put(1, 1);
+            w.put(5, (unsigned)(run + is_smaller + 1));
+        } else {
+            w.put(1, 0);
+        }
+        for (int k = 0; k < run; k += 3) put_triple(w, smallidx, sizesmall, &tmp[k]);
+        if (is_smaller != 0) {
+            smallidx += is_smaller;
+            if (is_smaller < 0) { smallnum = smaller; smaller = kMagic[smallidx - 1] / 2; }
+            else { smaller = smallnum; smallnum = kMagic[smallidx] / 2; }
+            sizesmall[0] = sizesmall[1] = sizesmall[2] = (unsigned)kMagic[smallidx];
+        }
+    }
+    const size_t nbytes = w.finish();
+    xdr_put_u32(o, (uint32_t)nbytes);
+    o.insert(o.end(), w.buf.begin(), w.buf.end());
+    for (size_t k = nbytes; k % 4 != 0; k++) o.push_back(0);
+    return TRJ_OK;
+}
+
+// Encode one frame into a caller-owned buffer; returns the byte count or a negative error.
+// cap must be at least trj_xtc_frame_bound(natoms).
+long long trj_xtc_frame_bound(int natoms) { return 128 + (long long)natoms * 16; }
+
+long long trj_xtc_encode_frame(unsigned char *out, long long cap, int natoms, long long step, float time, const float *box9,
+                               const float *x, float precision)
+{
+    std::vector<unsigned char> o;
+    o.reserve((size_t)natoms * 5 + 128);
+    xdr_put_u32(o, 1995u);
+    xdr_put_u32(o, (uint32_t)natoms);
+    xdr_put_u32(o, (uint32_t)(int32_t)step);
+    xdr_put_f32(o, time);
+    for (int k = 0; k < 9; k++) xdr_put_f32(o, box9[k]);
+    const int rc = xtc_encode_coords(o, natoms, x, precision);
+    if (rc != TRJ_OK) return rc;
+    if ((long long)o.size() > cap) return TRJ_ERR_RANGE;
+    memcpy(out, o.data(), o.size());
+    return (long long)o.size();
+}
+
+int trj_xtc_append(const char *path, int truncate, int natoms, long long step, float time, const float *box9, const float *x,
+                   float precision)
+{
+    std::vector<unsigned char> buf((size_t)trj_xtc_frame_bound(natoms));
+    const long long n = trj_xtc_encode_frame(buf.data(), (long long)buf.size(), natoms, step, time, box9, x, precision);
+    if (n < 0) return (int)n;
+    FILE *f = fopen(path, truncate ? "wb" : "ab");
+    if (!f) return TRJ_ERR_IO;
+    const size_t wr = fwrite(buf.data(), 1, (size_t)n, f);
+    const int cl = fclose(f);
+    return (wr == (size_t)n && cl == 0) ? TRJ_OK : TRJ_ERR_IO;
+}
+
+// Decode the frame that starts at `data`; *used receives its length. x must hold 3*natoms floats
+// (query natoms with x == NULL first: the header is parsed and *natoms set).
+int trj_xtc_decode_frame(const unsigned char *data, long long len, long long *used, int *natoms, long long *step, float *time,
+                         float *box9, float *x, float *precision)
+{
+    if (len == 0) return TRJ_EOF;
+    if (len < 56) return TRJ_ERR_FORMAT;
+    if (be32(data) != 1995u) return TRJ_ERR_FORMAT;
+    const int n = (int)be32(data + 4);
+    if (natoms) *natoms = n;
+    if (step) *step = (int32_t)be32(data + 8);
+    if (time) *time = bef32(data + 12);
+    if (box9) for (int k = 0; k < 9; k++) box9[k] = bef32(data + 16 + 4 * k);
+    if ((int)be32(data + 52) != n) return TRJ_ERR_FORMAT;
+    long long pos = 56;
+    if (n <= 9) {
+        if (len < pos + 12LL * n) return TRJ_ERR_FORMAT;
+        if (x) for (int i = 0; i < 3 * n; i++) x[i] = bef32(data + pos + 4 * i);
+        if (precision) *precision = 0.0f;
+        if (used) *used = pos + 12LL * n;
+        return TRJ_OK;
+    }
+    if (len < pos + 36) return TRJ_ERR_FORMAT;
+    const float prec = bef32(data + pos); pos += 4;
+    if (precision) *precision = prec;
+    int minint[3], maxint[3];
+    for (int d = 0; d < 3; d++) { minint[d] = (int32_t)be32(data + pos); pos += 4; }
+    for (int d = 0; d < 3; d++) { maxint[d] = (int32_t)be32(data + pos); pos += 4; }
+    int smallidx = (int)be32(data + pos); pos += 4;
+    const long long nbytes = be32(data + pos); pos += 4;
+    const long long padded = (nbytes + 3) / 4 * 4;
+    if (len < pos + padded) return TRJ_ERR_FORMAT;
+    if (used) *used = pos + padded;
+    if (!x) return TRJ_OK;
+    if (smallidx < kFirstIdx || smallidx >= kLastIdx) return TRJ_ERR_FORMAT;
+    unsigned int sizeint[3], bitsizeint[3] = { 0, 0, 0 };
+    for (int d = 0; d < 3; d++) sizeint[d] = (unsigned int)(maxint[d] - minint[d] + 1);
+    int bitsize;
+    if ((sizeint[0] | sizeint[1] | sizeint[2]) > 0xffffff) {
+        for (int d = 0; d < 3; d++) bitsizeint[d] = bits_of(sizeint[d]);
+        bitsize = 0;
+    } else bitsize = bits_of_product(sizeint);
+    int smaller = kMagic[(kFirstIdx > smallidx - 1) ? kFirstIdx : smallidx - 1] / 2;
+    int smallnum = kMagic[smallidx] / 2;
+    unsigned int sizesmall[3] = { (unsigned)kMagic[smallidx], (unsigned)kMagic[smallidx], (unsigned)kMagic[smallidx] };
+    BitReader r(data + pos, (size_t)nbytes);
+    const float inv = 1.0f / prec;
+    int run = 0, i = 0;
+    float *lfp = x;
+    while (i < n) {
+        int c[3], prev[3];
+        if (bitsize == 0) { c[0] = (int)r.get(bitsizeint[0]); c[1] = (int)r.get(bitsizeint[1]); c[2] = (int)r.get(bitsizeint[2]); }
+        else get_triple(r, bitsize, sizeint, c);
+        i++;
+        c[0] += minint[0]; c[1] += minint[1]; c[2] += minint[2];
+        prev[0] = c[0]; prev[1] = c[1]; prev[2] = c[2];
+        const unsigned flag = r.get(1);
+        int is_smaller = 0;
+        if (flag == 1) {
+            run = (int)r.get(5);
+            is_smaller = run % 3;
+            run -= is_smaller;
+            is_smaller--;
+        }
+        if (r.bad) return TRJ_ERR_FORMAT;
+        if (run > 0) {
+            if (i + run / 3 > n) return TRJ_ERR_FORMAT;
+            for (int k = 0; k < run; k += 3) {
+                int t[3];
+                get_triple(r, smallidx, sizesmall, t);
+                i++;
+                t[0] += prev[0] - smallnum; t[1] += prev[1] - smallnum; t[2] += prev[2] - smallnum;
+                if (k == 0) {
+                    // undo the interchange: the run's first small atom was the frame's earlier atom
+                    *lfp++ = t[0] * inv; *lfp++ = t[1] * inv; *lfp++ = t[2] * inv;
+                    *lfp++ = c[0] * inv; *lfp++ = c[1] * inv; *lfp++ = c[2] * inv;
+                } else {
+                    *lfp++ = t[0] * inv; *lfp++ = t[1] * inv; *lfp++ = t[2] * inv;
+                }
+                prev[0] = t[0]; prev[1] = t[1]; prev[2] = t[2];
+            }
+        } else {
+            *lfp++ = c[0] * inv; *lfp++ = c[1] * inv; *lfp++ = c[2] * inv;
+        }
+        smallidx += is_smaller;
+        if (is_smaller < 0) { smallnum = smaller; smaller = smallidx > kFirstIdx ? kMagic[smallidx - 1] / 2 : 0; }
+        else if (is_smaller > 0) { smaller = smallnum; smallnum = kMagic[smallidx] / 2; }
+        sizesmall[0] = sizesmall[1] = sizesmall[2] = (unsigned)kMagic[smallidx];
+        if (r.bad) return TRJ_ERR_FORMAT;
+    }
+    return TRJ_OK;
+}
+
+// ---------------------------------------------------------------- trr
+// Single-precision frame: header (magic 1993, "GMX_trn_file", block sizes, natoms, step, t,
+// lambda) then box, x, and optionally v and f.
+long long trj_trr_frame_bound(int natoms) { return 256 + 36LL * natoms; }
+
+long long trj_trr_encode_frame(unsigned char *out, long long cap, int natoms, long long step, float time, float lambda,
+                               const float *box9, const float *x, const float *v, const float *f)
+{
+    std::vector<unsigned char> o;
+    o.reserve(128 + (size_t)natoms * 12 * ((x ? 1 : 0) + (v ? 1 : 0) + (f ? 1 : 0)));
+    static const char version[] = "GMX_trn_file";
+    xdr_put_u32(o, 1993u);
+    xdr_put_u32(o, 13u);
+    xdr_put_u32(o, 12u);
+    for (int k = 0; k < 12; k++) o.push_back((unsigned char)version[k]);
+    const uint32_t vec = (uint32_t)natoms * 12u;
+    // ir, e, box, vir, pres, top, sym, x, v, f
+    const uint32_t sizes[10] = { 0, 0, box9 ? 36u : 0u, 0, 0, 0, 0, x ? vec : 0u, v ? vec : 0u, f ? vec : 0u };
+    for (int k = 0; k < 10; k++) xdr_put_u32(o, sizes[k]);
+    xdr_put_u32(o, (uint32_t)natoms);
+    xdr_put_u32(o, (uint32_t)(int32_t)step);
+    xdr_put_u32(o, 0u);                       // nre
+    xdr_put_f32(o, time);
+    xdr_put_f32(o, lambda);
+    if (box9) for (int k = 0; k < 9; k++) xdr_put_f32(o, box9[k]);
+    const float *blocks[3] = { x, v, f };
+    for (const float *b : blocks) {
+        if (!b) continue;
+        const size_t at = o.size();
+        o.resize(at + (size_t)natoms * 12);
+        unsigned char *p = o.data() + at;
+        for (size_t i = 0; i < 3 * (size_t)natoms; i++) {
+            uint32_t u; memcpy(&u, &b[i], 4);
+            p[4 * i] = (unsigned char)(u >> 24); p[4 * i + 1] = (unsigned char)(u >> 16); p[4 * i + 2] = (unsigned char)(u >> 8); p[4 * i + 3] = (unsigned char)u;
+        }
+    }
+    if ((long long)o.size() > cap) return TRJ_ERR_RANGE;
+    memcpy(out, o.data(), o.size());
+    return (long long)o.size();
+}
+
+int trj_trr_append(const char *path, int truncate, int natoms, long long step, float time, float lambda, const float *box9,
+                   const float *x, const float *v, const float *f)
+{
+    std::vector<unsigned char> buf((size_t)trj_trr_frame_bound(natoms));
+    const long long n = trj_trr_encode_frame(buf.data(), (long long)buf.size(), natoms, step, time, lambda, box9, x, v, f);
+    if (n < 0) return (int)n;
+    FILE *fp = fopen(path, truncate ? "wb" : "ab");
+    if (!fp) return TRJ_ERR_IO;
+    const size_t wr = fwrite(buf.data(), 1, (size_t)n, fp);
+    const int cl = fclose(fp);
+    return (wr == (size_t)n && cl == 0) ? TRJ_OK : TRJ_ERR_IO;
+}
+
+// Decode a single-precision trr frame. has[3] reports which of x, v, f were present.
+int trj_trr_decode_frame(const unsigned char *data, long long len, long long *used, int *natoms, long long *step, float *time,
+                         float *lambda, float *box9, float *x, float *v, float *f, int *has)
+{
+    if (len == 0) return TRJ_EOF;
+    if (len < 24 + 13 * 4 + 8) return TRJ_ERR_FORMAT;
+    if (be32(data) != 1993u || be32(data + 4) != 13u || be32(data + 8) != 12u || memcmp(data + 12, "GMX_trn_file", 12) != 0) return TRJ_ERR_FORMAT;
+    long long pos = 24;
+    uint32_t sizes[10];
+    for (int k = 0; k < 10; k++) { sizes[k] = be32(data + pos); pos += 4; }
+    const int n = (int)be32(data + pos); pos += 4;
+    if (natoms) *natoms = n;
+    if (step) *step = (int32_t)be32(data + pos);
+    pos += 4;
+    pos += 4;   // nre
+    if (sizes[2] != 0 && sizes[2] != 36u) return TRJ_ERR_FORMAT;       // double precision files are not handled
+    if (time) *time = bef32(data + pos);
+    pos += 4;
+    if (lambda) *lambda = bef32(data + pos);
+    pos += 4;
+    const long long body = (long long)sizes[0] + sizes[1] + sizes[2] + sizes[3] + sizes[4] + sizes[5] + sizes[6] + sizes[7] + sizes[8] + sizes[9];
+    if (len < pos + body) return TRJ_ERR_FORMAT;
+    if (used) *used = pos + body;
+    pos += sizes[0] + sizes[1];
+    if (sizes[2]) { if (box9) for (int k = 0; k < 9; k++) box9[k] = bef32(data + pos + 4 * k); pos += sizes[2]; }
+    pos += sizes[3] + sizes[4] + sizes[5] + sizes[6];
+    float *dst[3] = { x, v, f };
+    for (int b = 0; b < 3; b++) {
+        if (has) has[b] = sizes[7 + b] ? 1 : 0;
+        if (sizes[7 + b]) {
+            if (sizes[7 + b] != (uint32_t)n * 12u) return TRJ_ERR_FORMAT;
+            if (dst[b]) for (long long i = 0; i < 3LL * n; i++) dst[b][i] = bef32(data + pos + 4 * i);
+            pos += sizes[7 + b];
+        }
+    }
+    return TRJ_OK;
+}
+
+int trj_version(void) { return 1; }
+
+}  // extern "C"

@@ -412,7 +412,17 @@ int mdx_launch_update(mdx_system *s, bool do_tc, bool do_pr, bool virial)
     const int nb = (s->n + 255) / 256;
     hipLaunchKernelGGL(k_leapfrog, dim3(nb), dim3(256), 0, s->stream, s->n, s->x, s->xp, s->v, s->f, s->f_pme, s->f_s, s->sorted_of,
                        s->tcgrp, s->d, s->dt, do_tc ? 1 : 0, do_pr ? 1 : 0);
-    const float inv_dt = 1.0f / s->dt;
+    int rc = mdx_launch_constrain(s, 1.0f / s->dt, virial, s->lincs_iter);
+    if (rc) return rc;
+    // the constrained new positions become the state
+    float4 *t = s->x; s->x = s->xp; s->xp = t;
+    return MDX_OK;
+}
+
+// Constrain s->xp against the reference geometry s->x; velocities receive dx * inv_dt
+// (inv_dt = 0 leaves them alone, inv_dt = -1/dt serves the start-up velocity projection).
+int mdx_launch_constrain(mdx_system *s, float inv_dt, bool virial, int lincs_iter)
+{
     if (s->nsettle > 0) {
         const int nbw = (s->nsettle + 255) / 256;
         if (virial) hipLaunchKernelGGL(k_settle<true>, dim3(nbw), dim3(256), 0, s->stream, s->nsettle, s->settle_idx, s->x, s->xp, s->v, s->settle_doh, s->settle_dhh, inv_dt, s->d);
@@ -420,12 +430,10 @@ int mdx_launch_update(mdx_system *s, bool do_tc, bool do_pr, bool virial)
     }
     if (s->ncomp > 0) {
         const int nbc = (s->ncomp + 127) / 128;
-        if (virial) hipLaunchKernelGGL(k_lincs<true>, dim3(nbc), dim3(128), 0, s->stream, s->ncomp, s->comp_start, s->cons_ij, s->cons_len, s->x, s->xp, s->v, s->lincs_order, s->lincs_iter, inv_dt, s->d);
-        else hipLaunchKernelGGL(k_lincs<false>, dim3(nbc), dim3(128), 0, s->stream, s->ncomp, s->comp_start, s->cons_ij, s->cons_len, s->x, s->xp, s->v, s->lincs_order, s->lincs_iter, inv_dt, s->d);
+        if (virial) hipLaunchKernelGGL(k_lincs<true>, dim3(nbc), dim3(128), 0, s->stream, s->ncomp, s->comp_start, s->cons_ij, s->cons_len, s->x, s->xp, s->v, s->lincs_order, lincs_iter, inv_dt, s->d);
+        else hipLaunchKernelGGL(k_lincs<false>, dim3(nbc), dim3(128), 0, s->stream, s->ncomp, s->comp_start, s->cons_ij, s->cons_len, s->x, s->xp, s->v, s->lincs_order, lincs_iter, inv_dt, s->d);
     }
     MDX_CHECK(s, hipGetLastError());
-    // the constrained new positions become the state
-    float4 *t = s->x; s->x = s->xp; s->xp = t;
     return MDX_OK;
 }
 

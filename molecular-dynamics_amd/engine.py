@@ -29,8 +29,10 @@ SYMBOLS = [
     "mdx_get_step", "mdx_compute_forces", "mdx_get_forces", "mdx_get_energies", "mdx_get_virial", "mdx_step",
     "mdx_synchronize", "mdx_get_list_stats", "mdx_pop_energy_frames", "mdx_pop_pull_records",
     "mdx_enable_kernel_timing", "mdx_get_kernel_timing", "mdx_debug_time_nonbonded", "mdx_debug_set",
-    "mdx_debug_time_stage",
+    "mdx_debug_time_stage", "mdx_set_step", "mdx_generate_velocities", "mdx_constrain_start", "mdx_minimize",
+    "mdx_frame_ring", "mdx_capture_frame", "mdx_frame_wait",
 ]
+PROGRESS_FN = ctypes.CFUNCTYPE(None, ctypes.c_longlong, ctypes.c_double, ctypes.c_double, ctypes.c_double)
 
 
 class MdxError(RuntimeError):
@@ -88,10 +90,15 @@ def load_library(path: str | None = None):
     L.mdx_debug_time_nonbonded.argtypes = [vp, c_int, c_int, dp]
     L.mdx_debug_set.argtypes = [vp, c_int, c_int]
     L.mdx_debug_time_stage.argtypes = [vp, c_int, c_int, dp]
+    L.mdx_set_step.argtypes = [vp, ctypes.c_longlong]
+    L.mdx_generate_velocities.argtypes = [vp, c_d, ctypes.c_ulonglong]
+    L.mdx_constrain_start.argtypes = [vp]
+    L.mdx_minimize.argtypes = [vp, ctypes.c_longlong, c_d, c_d, dp, PROGRESS_FN]
+    L.mdx_frame_ring.argtypes = [vp, c_int]
+    L.mdx_capture_frame.argtypes = [vp, c_int, c_int]
+    L.mdx_frame_wait.argtypes = [vp, c_int, ctypes.POINTER(fp), ctypes.POINTER(fp), dp, llp]
     for name in SYMBOLS:
-        fn = getattr(L, name)
-        if fn.restype is c_int and name not in ("mdx_version",):
-            pass
+        getattr(L, name)        # every declared entry point must be exported
     if path is None:
         _LIB = L
     return L
@@ -281,6 +288,47 @@ class Engine:
 
     def synchronize(self):
         self._call("mdx_synchronize")
+
+    def get_step(self):
+        return int(self.lib.mdx_get_step(self.h))
+
+    def set_step(self, step):
+        self._call("mdx_set_step", ctypes.c_longlong(int(step)))
+
+    def generate_velocities(self, temperature, seed):
+        self._call("mdx_generate_velocities", float(temperature), ctypes.c_ulonglong(int(seed) & (2 ** 64 - 1)))
+
+    def constrain_start(self):
+        self._call("mdx_constrain_start")
+
+    def minimize(self, nsteps, emtol=1000.0, emstep=0.01, progress=None):
+        """Steepest descent; returns dict(steps, status, epot, fmax, epot0, fmax0)."""
+        res = np.zeros(6, np.float64)
+        cb = PROGRESS_FN(progress) if progress is not None else ctypes.cast(None, PROGRESS_FN)
+        self._call("mdx_minimize", ctypes.c_longlong(int(nsteps)), float(emtol), float(emstep), _p(res, ctypes.c_double), cb)
+        return dict(steps=int(res[0]), status=int(res[1]), epot=float(res[2]), fmax=float(res[3]),
+                    epot0=float(res[4]), fmax0=float(res[5]))
+
+    def frame_ring(self, nslots=4):
+        self._call("mdx_frame_ring", int(nslots))
+        self._nslots = int(nslots)
+
+    def capture_frame(self, slot, want_v=False):
+        self._call("mdx_capture_frame", int(slot), 1 if want_v else 0)
+
+    def frame_wait(self, slot):
+        """-> (step, x (N,3) f32 view of the pinned slot, v or None, box (3,3) f64). The views
+        are valid until the slot is captured into again."""
+        fp = ctypes.POINTER(ctypes.c_float)
+        px, pv = fp(), fp()
+        box = np.zeros(9, np.float64)
+        st = ctypes.c_longlong(0)
+        rc = self.lib.mdx_frame_wait(self.h, int(slot), ctypes.byref(px), ctypes.byref(pv), _p(box, ctypes.c_double), ctypes.byref(st))
+        if rc != 0:
+            raise MdxError(f"mdx_frame_wait failed ({rc})")
+        x = np.ctypeslib.as_array(px, shape=(self.n, 3))
+        v = np.ctypeslib.as_array(pv, shape=(self.n, 3)) if pv else None
+        return int(st.value), x, v, box.reshape(3, 3)
 
     def list_stats(self):
         st = (ctypes.c_longlong * 8)()
