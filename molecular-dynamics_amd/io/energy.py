@@ -1,0 +1,144 @@
+"""Energy output: the `.log` text blocks and the `.edr` energy file of an mdrun.
+
+`nstlog` / `nstenergy` set the cadence (/root/reference/mdp/production.mdp:10-11,
+nvt_complex.mdp:10-11); the pipeline declares `PREFIX.log` and `PREFIX.edr` as rule outputs
+(/root/reference/Snakefile:218,258,299-300). The `.log` follows the familiar layout (step/time
+header, five right-aligned 15-column terms per row, closing `Performance:` line in ns/day and
+hour/ns). The `.edr` written here is a plain XDR stream of this package's own design (magic
+-55556, term names and units, then one record of step, time and float64 values per frame); it
+is read back by `read_edr` and is not the enx layout of `gmx energy`.
+"""
+from __future__ import annotations
+
+import struct
+import time as _time
+
+TERMS = [  # (engine key, printed name, unit)
+    ("BOND", "Bond", "kJ/mol"), ("ANGLE", "Angle", "kJ/mol"), ("DIH", "Proper Dih.", "kJ/mol"),
+    ("LJ14", "LJ-14", "kJ/mol"), ("COUL14", "Coulomb-14", "kJ/mol"), ("LJ", "LJ (SR)", "kJ/mol"),
+    ("DISPCORR", "Disper. corr.", "kJ/mol"), ("COUL_SR", "Coulomb (SR)", "kJ/mol"),
+    ("COUL_RECIP", "Coul. recip.", "kJ/mol"), ("POSRES", "Position Rest.", "kJ/mol"),
+    ("PULL", "COM Pull En.", "kJ/mol"), ("POT", "Potential", "kJ/mol"), ("KIN", "Kinetic En.", "kJ/mol"),
+    ("TOTAL", "Total Energy", "kJ/mol"), ("CONSERVED", "Conserved En.", "kJ/mol"), ("TEMP", "Temperature", "K"),
+    ("PRES", "Pressure", "bar"), ("VOLUME", "Volume", "nm^3"), ("DENSITY", "Density", "kg/m^3"),
+]
+
+
+def frame_terms(e: dict, total_mass_amu: float | None = None) -> dict:
+    """Engine energy dict -> printed terms. The exclusion correction and the Ewald self term are
+    folded into `Coul. recip.`, which is where mdrun reports them."""
+    out = dict(e)
+    out["COUL_RECIP"] = e["COUL_RECIP"] + e["COUL_EXCL"]
+    out["TOTAL"] = e["POT"] + e["KIN"]
+    vol = e.get("VOLUME", 0.0)
+    out["DENSITY"] = (total_mass_amu * 1.66053906660 / vol) if (total_mass_amu and vol > 0) else 0.0
+    return out
+
+
+def format_energy_block(step: int, time: float, terms: dict, skip_zero=("POSRES", "PULL", "DISPCORR")) -> str:
+    rows = ["           Step           Time", "%15d%15.5f" % (step, time), "", "   Energies (kJ/mol)"]
+    items = [(name, terms[key]) for key, name, _ in TERMS if key in terms and not (key in skip_zero and terms[key] == 0.0)]
+    for s in range(0, len(items), 5):
+        chunk = items[s:s + 5]
+        rows.append("".join("%15s" % n for n, _ in chunk))
+        rows.append("".join("%15.5e" % v for _, v in chunk))
+    rows.append("")
+    return "\n".join(rows) + "\n"
+
+
+class LogWriter:
+    def __init__(self, path: str, append: bool = False):
+        self.f = open(path, "a" if append else "w")
+        self.sums = {}
+        self.count = 0
+
+    def header(self, lines):
+        self.f.write("\n".join(lines) + "\n\n")
+        self.f.flush()
+
+    def energies(self, step, time, terms):
+        self.f.write(format_energy_block(step, time, terms))
+        for k, v in terms.items():
+            self.sums[k] = self.sums.get(k, 0.0) + v
+        self.count += 1
+
+    def note(self, text):
+        self.f.write(text.rstrip("\n") + "\n")
+        self.f.flush()
+
+    def finish(self, nsteps_done: int, dt_ps: float, wall_s: float, last_step: int):
+        if self.count:
+            self.f.write("\t<======  ###############  ==>\n\t<====  A V E R A G E S  ====>\n\t<==  ###############  ======>\n\n")
+            self.f.write("\tStatistics over %d steps using %d frames\n\n" % (last_step + 1, self.count))
+            avg = {k: v / self.count for k, v in self.sums.items()}
+            self.f.write(format_energy_block(last_step, last_step * dt_ps, avg).split("\n", 3)[3])
+        self.f.write(performance_block(nsteps_done, dt_ps, wall_s))
+        self.f.write("Finished mdrun on %s\n" % _time.strftime("%a %b %d %H:%M:%S %Y"))
+        self.f.flush()
+
+    def flush(self):
+        self.f.flush()
+
+    def close(self):
+        if not self.f.closed:
+            self.f.close()
+
+
+def performance_block(nsteps: int, dt_ps: float, wall_s: float) -> str:
+    wall_s = max(wall_s, 1e-9)
+    ns = nsteps * dt_ps * 1e-3
+    nsday = ns * 86400.0 / wall_s if nsteps > 0 else 0.0
+    hourns = (wall_s / 3600.0) / ns if ns > 0 else 0.0
+    return ("\n               Core t (s)   Wall t (s)        (%%)\n       Time: %12.3f %12.3f      100.0\n"
+            "                 (ns/day)    (hour/ns)\nPerformance: %12.3f %12.3f\n" % (wall_s, wall_s, nsday, hourns))
+
+
+EDR_MAGIC = -55556
+
+
+class EdrWriter:
+    def __init__(self, path: str, append: bool = False):
+        self.keys = [k for k, _, _ in TERMS]
+        self.f = open(path, "ab" if append else "wb")
+        if not append or self.f.tell() == 0:
+            self.f.write(struct.pack(">ii", EDR_MAGIC, len(TERMS)))
+            for _, name, unit in TERMS:
+                for s in (name, unit):
+                    b = s.encode()
+                    self.f.write(struct.pack(">i", len(b)) + b + b"\0" * (-len(b) % 4))
+
+    def frame(self, step, time, terms):
+        self.f.write(struct.pack(">qd", int(step), float(time)))
+        self.f.write(struct.pack(">%dd" % len(self.keys), *[float(terms.get(k, 0.0)) for k in self.keys]))
+
+    def flush(self):
+        self.f.flush()
+
+    def close(self):
+        if not self.f.closed:
+            self.f.close()
+
+
+def read_edr(path: str):
+    """-> (names, units, list of (step, time, values))."""
+    with open(path, "rb") as f:
+        data = f.read()
+    magic, n = struct.unpack_from(">ii", data, 0)
+    if magic != EDR_MAGIC:
+        raise ValueError(f"{path}: not an energy file written by this mdrun")
+    pos = 8
+    names, units = [], []
+    for _ in range(n):
+        for dst in (names, units):
+            (ln,) = struct.unpack_from(">i", data, pos)
+            pos += 4
+            dst.append(data[pos:pos + ln].decode())
+            pos += ln + (-ln % 4)
+    frames = []
+    rec = 16 + 8 * n
+    while pos + rec <= len(data):
+        step, t = struct.unpack_from(">qd", data, pos)
+        vals = struct.unpack_from(">%dd" % n, data, pos + 16)
+        frames.append((step, t, list(vals)))
+        pos += rec
+    return names, units, frames
