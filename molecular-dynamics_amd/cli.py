@@ -30,6 +30,9 @@ def main(argv=None) -> int:
         return runner.grompp(rest)
     if tool == "mdrun":
         return runner.mdrun(rest)
+    if tool == "make_ndx" and (runner.find_real_gmx() is None or any(
+            os.path.isfile(x + ".mdx") for x in rest if not x.startswith("-"))):
+        return runner.make_ndx(rest)
     real = runner.find_real_gmx()
     if real is None:
         sys.stderr.write(f"gmx {tool}: this tool is not part of the MD engine and no GROMACS installation was found "

@@ -176,14 +176,15 @@ static int xtc_encode_coords(std::vector<unsigned char> &o, int natoms, const fl
         bitsize = bits_of_product(sizeint);
     }
     int smallidx = kFirstIdx;
-    while (smallidx < kLastIdx && kMagic[smallidx] < mindiff) smallidx++;
+    while (smallidx < kLastIdx - 1 && kMagic[smallidx] < mindiff) smallidx++;
     xdr_put_u32(o, (uint32_t)smallidx);
-    const int maxidx = (kLastIdx < smallidx + 8) ? kLastIdx : smallidx + 8;
+    // the table's last entry bounds both indices (frames with > 16777216 between all neighbours)
+    const int maxidx = (kLastIdx - 1 < smallidx + 8) ? kLastIdx - 1 : smallidx + 8;
     const int minidx = maxidx - 8;
     int smaller = kMagic[(kFirstIdx > smallidx - 1) ? kFirstIdx : smallidx - 1] / 2;
     int smallnum = kMagic[smallidx] / 2;
     unsigned int sizesmall[3] = { (unsigned)kMagic[smallidx], (unsigned)kMagic[smallidx], (unsigned)kMagic[smallidx] };
-    const int larger = kMagic[maxidx < kLastIdx ? maxidx : kLastIdx - 1] / 2;
+    const int larger = kMagic[maxidx] / 2;
     BitWriter w;
     w.buf.reserve((size_t)natoms * 5);
     int prev[3] = { 0, 0, 0 };

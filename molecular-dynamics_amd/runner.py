@@ -250,6 +250,64 @@ def grompp(argv, out=sys.stdout, err=sys.stderr) -> int:
 
 
 # ------------------------------------------------------------------------------------------
+# make_ndx (the non-interactive uses of the pipeline)
+# ------------------------------------------------------------------------------------------
+def make_ndx(argv, stdin=None, out=sys.stdout, err=sys.stderr) -> int:
+    """`gmx make_ndx -f conf.gro -o index.ndx` fed with `q`
+    (/root/reference/scripts/add_active_site_group.py:73-77): default groups from residue and
+    atom names. The editing commands the pipeline pipes in are handled too: `A|B`, `A&B`,
+    `name N text`, `del N`, `q` (/root/reference/Snakefile:1051)."""
+    p = argparse.ArgumentParser(prog="gmx make_ndx", allow_abbrev=False)
+    p.add_argument("-f", default=None)
+    p.add_argument("-n", default=None)
+    p.add_argument("-o", default="index.ndx")
+    a, _ = p.parse_known_args(argv)
+    try:
+        if a.f is None and a.n is None:
+            raise InputError("make_ndx needs -f or -n")
+        if a.n:
+            groups = ndxio.read_ndx(a.n)
+        else:
+            if tprio.is_run_input(a.f) or os.path.isfile(a.f + ".mdx"):
+                sysm, _, _ = tprio.load_run_input(a.f + ".mdx" if os.path.isfile(a.f + ".mdx") else a.f)
+                groups = ndxio.default_groups(sysm.resname, sysm.atomname)
+            else:
+                g = groio.read_gro(a.f)
+                groups = ndxio.default_groups(g.resname, g.atomname)
+        text = (stdin if stdin is not None else sys.stdin).read() if (stdin is not None or not sys.stdin.isatty()) else "q\n"
+        for line in text.splitlines():
+            cmd = line.strip()
+            if not cmd:
+                continue
+            if cmd == "q":
+                break
+            w = cmd.split()
+            if w[0] == "name" and len(w) >= 3:
+                groups.names[int(w[1])] = w[2]
+            elif w[0] == "del" and len(w) >= 2:
+                k = int(w[1]); del groups.names[k]; del groups.atoms[k]
+            elif "|" in cmd or "&" in cmd:
+                op = "|" if "|" in cmd else "&"
+                lhs, rhs = (t.strip() for t in cmd.split(op, 1))
+
+                def pick(tok):
+                    return groups.atoms[int(tok)] if tok.lstrip("-").isdigit() else groups[tok.strip('"')]
+                A, B = pick(lhs), pick(rhs)
+                res = np.union1d(A, B) if op == "|" else np.intersect1d(A, B)
+                nm = lambda t: groups.names[int(t)] if t.lstrip("-").isdigit() else t.strip('"')
+                groups.add(f"{nm(lhs)}_{nm(rhs)}" if op == "|" else f"{nm(lhs)}_&_{nm(rhs)}", res)
+            else:
+                err.write(f"make_ndx: command '{cmd}' is not supported and was skipped\n")
+        ndxio.write_ndx(a.o, groups)
+        for i, (n, at) in enumerate(zip(groups.names, groups.atoms)):
+            out.write("%3d %-20s: %5d atoms\n" % (i, n, len(at)))
+        return 0
+    except (InputError, ValueError, KeyError, IndexError, OSError) as e:
+        err.write(f"\nProgram:     gmx make_ndx ({PROGRAM})\n\nFatal error:\n{e}\n")
+        return 1
+
+
+# ------------------------------------------------------------------------------------------
 # mdrun
 # ------------------------------------------------------------------------------------------
 def _mdrun_parser():
