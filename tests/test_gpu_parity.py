@@ -139,3 +139,21 @@ def test_cutoff_1p2_pull_settings(small_water):
     e.close()
     assert relrms(f, o["f"]) < FTOL
     assert abs(en["LJ"] - o["e_lj"]) < ETOL * abs(o["e_lj"])
+
+
+def test_pipeline_dialect_system_total_force():
+    """The system parsed from the pipeline-style topology fixture (pdb2gmx-like protein block,
+    acpype-like ligand include, tip3p/ions includes) evaluated by the HIP path and by the oracle."""
+    import os
+    from mdx.io import gro, top
+    td = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "topdialect")
+    g = gro.read_gro(os.path.join(td, "complex.gro"))
+    s = top.build_system(top.read_top(os.path.join(td, "ion.top"), defines={"POSRES": ""}), g, constraints="h-bonds", posres_ref=g)
+    s.x = s.x.astype(np.float32).astype(np.float64)
+    # 2.4 nm cube: the cutoff and pair-list radius have to fit twice into the box
+    e = eng.Engine(s, rc=0.9, rlist=1.0, nstcalcenergy=1, use_posres=True)
+    f, en = e.compute(eng.F_ALL & ~eng.F_PULL & ~eng.F_POSRES)
+    ref = R.all_forces(s, 0.9, e.beta, e.grid, nthreads=8)
+    e.close()
+    assert relrms(f, ref["f"]) < FTOL
+    assert np.isfinite(list(en.values())).all()
