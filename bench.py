@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prep-steps", type=int, default=2000)
+    ap.add_argument("--no-output", action="store_true", help="diagnostic: skip the trajectory output the .mdp asks for")
+    ap.add_argument("--encoders", type=int, default=3, help="host threads compressing trajectory frames")
     args = ap.parse_args()
 
     import torch
@@ -112,16 +114,50 @@ def main():
     # ---- warmup
     e.step(args.warmup); e.synchronize()
     e.pop_energy_frames()
+    # ---- mdp-mandated output inside the timed region: compressed frames of the whole system every
+    # nstxout-compressed steps (/root/reference/mdp/production.mdp:12-13, pull_short.mdp:8), written
+    # by encoder threads while the step loop keeps the GPU queue filled
+    nst_xtc = 0 if args.no_output else (10 if args.workload == "production" else 500)
+    pipe = xtc = None
+    xtc_path = None
+    if nst_xtc:
+        import tempfile
+        from mdx.io import traj
+        from mdx.output import FramePipeline
+        xtc_path = os.path.join(tempfile.gettempdir(), "mdx_bench_rank%d_%d.xtc" % (rank, os.getpid()))
+        xtc = traj.XtcWriter(xtc_path, s.natoms, precision=1000.0)
+        e.frame_ring(8)
+        pipe = FramePipeline(e, 8, xtc, None, None, dt, 0.0, nthreads=args.encoders)
     e.enable_kernel_timing(True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    e.step(args.steps)
+    if nst_xtc:
+        done = 0
+        while done < args.steps:
+            if (e.get_step() % nst_xtc) == 0:
+                slot = pipe.acquire_slot()
+                e.capture_frame(slot)
+                pipe.submit(slot, True, False, False)
+            n = min(args.steps - done, nst_xtc - e.get_step() % nst_xtc)
+            e.step(n)
+            done += n
+    else:
+        e.step(args.steps)
     e.synchronize(); torch.cuda.synchronize()
+    if pipe is not None:
+        pipe.finish()
+        xtc.close()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    xtc_frames = xtc.frames if xtc is not None else 0
+    xtc_bytes = os.path.getsize(xtc_path) if xtc_path else 0
+    if pipe is not None and pipe.error is not None:
+        raise pipe.error
+    if xtc_path:
+        os.remove(xtc_path)
     nb_ms, nb_launches = e.kernel_timing()
     e.enable_kernel_timing(False)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -153,9 +189,15 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 5), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("pseudo-complex S2 (%d atoms, dodecahedron d=%.1f nm), production.mdp settings, "
-                                    "%s barostat, energies every 10 steps" % (s.natoms, args.box, args.pcoupl))
+                                    "%s barostat, energies every 10 steps, %s" % (
+                                        s.natoms, args.box, args.pcoupl,
+                                        "xtc frame of the whole system every 10 steps compressed and written" if nst_xtc
+                                        else "NO trajectory output (diagnostic run)"))
                        if args.workload == "production" else
-                       ("pseudo-complex S2 (%d atoms), pull_short.mdp settings, constant-force COM pull, one replica per GPU" % s.natoms),
+                       ("pseudo-complex S2 (%d atoms), pull_short.mdp settings, constant-force COM pull, one replica per GPU, "
+                        "xtc every 500 steps" % s.natoms),
+                       "output": {"xtc_every": nst_xtc, "xtc_frames": xtc_frames, "xtc_MB": round(xtc_bytes / 1e6, 2),
+                                  "encoder_threads": args.encoders if nst_xtc else 0},
                        "natoms": s.natoms, "dt_ps": dt, "rc_nm": e.rc, "rlist_nm": round(e.rlist, 4), "nstlist": args.nstlist,
                        "pme_grid": list(e.grid), "parallelism": "replicas x%d" % world},
             "pair_interactions_per_s": round(n_rc / nb_avg_s, 1) if nb_avg_s > 0 else None,

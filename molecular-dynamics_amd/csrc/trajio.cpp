@@ -39,25 +39,28 @@ static const float kMaxAbs = (float)(INT_MAX - 2);
 
 // ---------------------------------------------------------------- bit stream (MSB first)
 struct BitWriter {
-    std::vector<unsigned char> buf;
-    unsigned int acc = 0;
+    std::vector<unsigned char> buf;     // sized up front by the caller for the worst case (no growth checks in put)
+    size_t len = 0;
+    uint64_t acc = 0;                   // low `nacc` bits are pending, nacc < 8 between calls
     int nacc = 0;
-    void put(int nbits, unsigned int v)
+    void reserve_bytes(size_t n) { if (buf.size() < n) buf.resize(n); }
+    // append the low `nbits` (<= 32) bits of v, most significant first
+    inline void put(int nbits, unsigned int v)
     {
-        while (nbits > 0) {
-            const int take = nbits > 8 ? 8 : nbits;
-            const unsigned int chunk = (v >> (nbits - take)) & ((1u << take) - 1u);
-            acc = (acc << take) | chunk;
-            nacc += take;
-            nbits -= take;
-            while (nacc >= 8) { buf.push_back((unsigned char)((acc >> (nacc - 8)) & 0xFFu)); nacc -= 8; }
-            acc &= (1u << nacc) - 1u;
-        }
+        if (nbits <= 0) return;
+        const uint64_t mask = nbits >= 32 ? 0xFFFFFFFFull : ((1ull << nbits) - 1ull);
+        acc = (acc << nbits) | ((uint64_t)v & mask);
+        nacc += nbits;
+        while (nacc >= 8) { buf[len++] = (unsigned char)(acc >> (nacc - 8)); nacc -= 8; }
+        acc &= (1ull << nacc) - 1ull;
     }
     size_t finish()
     {
-        if (nacc > 0) { buf.push_back((unsigned char)((acc << (8 - nacc)) & 0xFFu)); nacc = 0; acc = 0; }
-        return buf.size();
+        if (nacc > 0) {
+            if (len + 1 > buf.size()) buf.resize(len + 1);
+            buf[len++] = (unsigned char)((acc << (8 - nacc)) & 0xFFu); nacc = 0; acc = 0;
+        }
+        return len;
     }
 };
 
@@ -101,6 +104,17 @@ static int bits_of_product(const unsigned int sizes[3])
 // three numbers, radices sizes[1], sizes[2]: value = (n0*s1 + n1)*s2 + n2, sent low byte first
 static void put_triple(BitWriter &w, int nbits, const unsigned int sizes[3], const unsigned int nums[3])
 {
+    if (nbits <= 64) {
+        // the value fits a machine word: whole bytes low byte first, then the remaining high bits
+        const uint64_t v = ((uint64_t)nums[0] * sizes[1] + nums[1]) * sizes[2] + nums[2];
+        const int k = nbits >> 3, r = nbits & 7;
+        // as one big-endian bit string: the k low bytes reversed, followed by the r remaining high bits
+        uint64_t word = k ? (__builtin_bswap64(v) >> (64 - 8 * k)) : 0;
+        if (r) word = (k == 8 ? 0 : (word << r)) | (k == 8 ? 0 : (v >> (8 * k)));
+        if (nbits > 32) { w.put(nbits - 32, (unsigned int)(word >> 32)); w.put(32, (unsigned int)word); }
+        else w.put(nbits, (unsigned int)word);
+        return;
+    }
     unsigned __int128 v = nums[0];
     v = v * sizes[1] + nums[1];
     v = v * sizes[2] + nums[2];
@@ -146,7 +160,10 @@ static int xtc_encode_coords(std::vector<unsigned char> &o, int natoms, const fl
     }
     if (precision <= 0) precision = 1000.0f;
     xdr_put_f32(o, precision);
-    std::vector<int> ip(3 * (size_t)natoms + 3);
+    // per-thread scratch that only grows: no per-frame allocation or zero fill
+    static thread_local std::vector<int> ip_scratch;
+    if (ip_scratch.size() < 3 * (size_t)natoms + 3) ip_scratch.resize(3 * (size_t)natoms + 3);
+    int *const ip = ip_scratch.data();
     int minint[3] = { INT_MAX, INT_MAX, INT_MAX }, maxint[3] = { INT_MIN, INT_MIN, INT_MIN };
     int mindiff = INT_MAX, old[3] = { 0, 0, 0 };
     for (int i = 0; i < natoms; i++) {
@@ -185,12 +202,14 @@ static int xtc_encode_coords(std::vector<unsigned char> &o, int natoms, const fl
     int smallnum = kMagic[smallidx] / 2;
     unsigned int sizesmall[3] = { (unsigned)kMagic[smallidx], (unsigned)kMagic[smallidx], (unsigned)kMagic[smallidx] };
     const int larger = kMagic[maxidx] / 2;
+    static thread_local std::vector<unsigned char> bits_scratch;
     BitWriter w;
-    w.buf.reserve((size_t)natoms * 5);
+    w.buf.swap(bits_scratch);
+    w.reserve_bytes((size_t)natoms * 16 + 64);     // > 3 x 32 bits + run flags per atom
     int prev[3] = { 0, 0, 0 };
     int prevrun = -1;
     int i = 0;
-    int *c = ip.data();
+    int *c = ip;
     unsigned int tmp[30];
     while (i < natoms) {
         bool is_small = false;
@@ -245,7 +264,8 @@ static int xtc_encode_coords(std::vector<unsigned char> &o, int natoms, const fl
     }
     const size_t nbytes = w.finish();
     xdr_put_u32(o, (uint32_t)nbytes);
-    o.insert(o.end(), w.buf.begin(), w.buf.end());
+    o.insert(o.end(), w.buf.begin(), w.buf.begin() + (long)nbytes);
+    bits_scratch.swap(w.buf);
     for (size_t k = nbytes; k % 4 != 0; k++) o.push_back(0);
     return TRJ_OK;
 }

@@ -63,19 +63,30 @@ class XtcWriter:
         self.natoms = int(natoms)
         self.precision = float(precision)
         self.f = open(path, "ab" if append else "wb")
-        self.buf = (ctypes.c_ubyte * int(self.lib.trj_xtc_frame_bound(self.natoms)))()
+        import threading
+        self._tls = threading.local()
         self.frames = 0
 
-    def write(self, step: int, time: float, box, x):
+    def encode(self, step: int, time: float, box, x) -> bytes:
+        """One frame as bytes; safe to call from several threads at once (per-thread buffers)."""
         x = _f32(x); box = _f32(np.asarray(box).reshape(9))
         if x.shape != (self.natoms, 3):
             raise TrajError(f"frame has shape {x.shape}, expected ({self.natoms}, 3)")
-        n = self.lib.trj_xtc_encode_frame(self.buf, len(self.buf), self.natoms, int(step), float(time), _fptr(box), _fptr(x),
-                                          self.precision)
+        tl = self._tls
+        buf = getattr(tl, "buf", None)
+        if buf is None:
+            buf = tl.buf = (ctypes.c_ubyte * int(self.lib.trj_xtc_frame_bound(self.natoms)))()
+        n = self.lib.trj_xtc_encode_frame(buf, len(buf), self.natoms, int(step), float(time), _fptr(box), _fptr(x), self.precision)
         if n < 0:
             raise TrajError(f"xtc encoding failed ({n}): coordinate out of range or not finite")
-        self.f.write(memoryview(self.buf)[:n])
+        return bytes(memoryview(buf)[:n])
+
+    def write_bytes(self, b: bytes):
+        self.f.write(b)
         self.frames += 1
+
+    def write(self, step: int, time: float, box, x):
+        self.write_bytes(self.encode(step, time, box, x))
 
     def flush(self):
         self.f.flush()

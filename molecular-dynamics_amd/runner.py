@@ -358,45 +358,6 @@ def _seed(val):
     return int(val)
 
 
-class _FrameWriter(threading.Thread):
-    """Waits for captured frames and encodes them while the main thread keeps enqueuing steps."""
-
-    def __init__(self, eng, nslots, xtc, trr, xtc_sel, dt, tinit):
-        super().__init__(daemon=True)
-        self.eng, self.xtc, self.trr, self.sel = eng, xtc, trr, xtc_sel
-        self.dt, self.tinit = dt, tinit
-        self.q = queue.Queue()
-        self.free = queue.Queue()
-        for s in range(nslots):
-            self.free.put(s)
-        self.error = None
-
-    def submit(self, slot, want_xtc, want_trr_x, want_trr_v):
-        self.q.put((slot, want_xtc, want_trr_x, want_trr_v))
-
-    def run(self):
-        while True:
-            item = self.q.get()
-            if item is None:
-                return
-            slot, wx, tx, tv = item
-            try:
-                step, x, v, box = self.eng.frame_wait(slot)
-                t = self.tinit + step * self.dt
-                if wx and self.xtc is not None:
-                    self.xtc.write(step, t, box, x if self.sel is None else x[self.sel])
-                if (tx or tv) and self.trr is not None:
-                    self.trr.write(step, t, box, x if tx else None, v if tv else None)
-            except Exception as e:      # keep draining so the main thread never blocks on a slot
-                self.error = e
-            finally:
-                self.free.put(slot)
-
-    def finish(self):
-        self.q.put(None)
-        self.join()
-
-
 def mdrun(argv, out=sys.stdout, err=sys.stderr) -> int:
     a, extra = _mdrun_parser().parse_known_args(argv)
     t_start = time.time()
@@ -576,12 +537,12 @@ def mdrun(argv, out=sys.stdout, err=sys.stderr) -> int:
             if not appending:
                 _backup(f_trr)
             trr = traj.TrrWriter(f_trr, sysm.natoms, append=appending)
-        nslots = 6
+        nslots = 8
         writer = None
         if xtc is not None or trr is not None:
             eng.frame_ring(nslots)
-            writer = _FrameWriter(eng, nslots, xtc, trr, sel, dt, tinit)
-            writer.start()
+            from .output import FramePipeline
+            writer = FramePipeline(eng, nslots, xtc, trr, sel, dt, tinit, nthreads=2)
         if not appending:
             _backup(f_edr)
         edr = enio.EdrWriter(f_edr, append=appending)
@@ -595,7 +556,7 @@ def mdrun(argv, out=sys.stdout, err=sys.stderr) -> int:
                 return          # the part that ended here already wrote this step's frame
             wx, tx, tv = due(nst_xtc, s) and xtc is not None, due(nst_x, s), due(nst_v, s)
             if writer is not None and (wx or tx or tv):
-                slot = writer.free.get()
+                slot = writer.acquire_slot()
                 eng.capture_frame(slot, want_v=tv)
                 writer.submit(slot, wx, tx, tv)
 
