@@ -84,7 +84,8 @@ def main():
     ap.add_argument("--box", type=float, default=12.5)
     ap.add_argument("--workload", default="production", choices=["production", "smd"])
     ap.add_argument("--pcoupl", default="c-rescale", choices=["c-rescale", "parrinello-rahman", "no"])
-    ap.add_argument("--nstlist", type=int, default=10)
+    ap.add_argument("--nstlist", type=int, default=20,
+                    help="pair-list lifetime; the .mdp value 10 is a lower bound that mdrun raises on GPUs")
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prep-steps", type=int, default=2000)

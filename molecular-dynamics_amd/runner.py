@@ -422,9 +422,11 @@ def mdrun(argv, out=sys.stdout, err=sys.stderr) -> int:
     if integrator != "md":
         tcoupl, pcoupl = "no", 0
     tc_groups = m.words("tc_grps") if tcoupl != "no" else None
+    # like mdrun on a GPU, dynamics treats the file's nstlist as a lower bound: the list lifetime is
+    # raised to 20 steps and the pair-list radius follows from the buffer estimate (`-nstlist` overrides)
     nstlist = max(1, min(m.i("nstlist"), 20))
-    if integrator == "md" and nstlist < 10:
-        nstlist = 10
+    if integrator == "md":
+        nstlist = int(a.nstlist) if a.nstlist else 20
     try:
         eng = Engine(
             sysm, rc=rc_, nstlist=nstlist, ewald_rtol=m.f("ewald_rtol"), pme=True, fourierspacing=m.f("fourierspacing"),
