@@ -154,53 +154,6 @@ __global__ __launch_bounds__(256) void k_posres(int n, const int *__restrict__ i
     if (ENERGY) accum_ev(e, v9, dw, MDX_E_POSRES);
 }
 
-// Ewald correction for excluded pairs: E = -qq erf(beta r)/r. One thread per atom walks its
-// exclusion list and accumulates only its own force (every pair is visited from both ends), so
-// the force is written with a plain add and no atomics. For beta r < 0.5 a series avoids the
-// cancellation between erf(z)/z and 2/sqrt(pi) exp(-z^2).
-template <bool ENERGY>
-__global__ __launch_bounds__(256) void k_excl_corr(int n, const int *__restrict__ es, const int *__restrict__ el,
-                                                   const float4 *__restrict__ x, float *__restrict__ f, DevState *dw, float beta)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    double e = 0.0; float v9[9] = { 0 };
-    if (i < n) {
-        const float4 xi = x[i];
-        const int k0 = es[i], k1 = es[i + 1];
-        float3 fsum = make_float3(0.0f, 0.0f, 0.0f);
-        if (xi.w != 0.0f) {
-            const float b3 = beta * beta * beta;
-            for (int k = k0; k < k1; k++) {
-                const float4 xj = x[el[k]];
-                const float qq = MDX_ONE_4PI_EPS0 * xi.w * xj.w;
-                if (qq == 0.0f) continue;
-                // excluded atoms belong to one molecule, and molecules are kept whole in the state
-                const float3 d = xyz(xi) - xyz(xj);
-                const float r2 = dot3(d, d);
-                const float r = sqrtf(r2), z = beta * r, z2 = z * z;
-                float erf_over_z, g; // g = (erf(z)/z - 2/sqrt(pi) exp(-z^2)) / z^2
-                if (z < 0.5f) {
-                    // erf(z)/z = 2/sqrt(pi) (1 - z^2/3 + z^4/10 - z^6/42 + z^8/216 - z^10/1320)
-                    erf_over_z = MDX_2_SQRTPI * (1.0f + z2 * (-1.0f / 3.0f + z2 * (0.1f + z2 * (-1.0f / 42.0f + z2 * (1.0f / 216.0f - z2 * (1.0f / 1320.0f))))));
-                    // g = 2/sqrt(pi) (2/3 - 2 z^2/5 + z^4/7 - z^6/27 + z^8/132 - z^10/780)
-                    g = MDX_2_SQRTPI * (2.0f / 3.0f + z2 * (-0.4f + z2 * (1.0f / 7.0f + z2 * (-1.0f / 27.0f + z2 * (1.0f / 132.0f - z2 * (1.0f / 780.0f))))));
-                } else {
-                    const float ex = __expf(-z2);
-                    const float er = 1.0f - ex * mdx_erfcx_poly(z);
-                    erf_over_z = er / z;
-                    g = (erf_over_z - MDX_2_SQRTPI * ex) / z2;
-                }
-                // E = -qq beta erf(z)/z ; F_i = -dE/dr d/r = -qq beta^3 g d
-                const float3 fi = (-qq * b3 * g) * d;
-                fsum = fsum + fi;
-                if (ENERGY) { e += -0.5 * (double)qq * beta * erf_over_z; outer_acc(v9, d, 0.5f * fi); }
-            }
-        }
-        if (k1 > k0) { f[3 * i] += fsum.x; f[3 * i + 1] += fsum.y; f[3 * i + 2] += fsum.z; }
-    }
-    if (ENERGY) accum_ev(e, v9, dw, MDX_E_COUL_EXCL);
-}
-
 #define LAUNCH_EV(kern, n, ...)                                                                     \
     if ((n) > 0) {                                                                                  \
         const int nb_ = ((n) + 255) / 256;                                                          \
@@ -219,9 +172,7 @@ int mdx_launch_bonded(mdx_system *s, bool energy, unsigned flags)
     if (flags & MDX_F_POSRES) {
         LAUNCH_EV(k_posres, s->nposres, s->posres_idx, s->posres_ref, s->posres_k, s->x, s->f, s->d);
     }
-    if (flags & MDX_F_EXCL) {
-        if (s->n_excl_pairs > 0) { LAUNCH_EV(k_excl_corr, s->n, s->excl_start, s->excl_list, s->x, s->f, s->d, s->beta); }
-    }
+    // the Ewald correction of excluded pairs is evaluated by the nonbonded kernel on the pair list
     MDX_CHECK(s, hipGetLastError());
     return MDX_OK;
 }

@@ -554,7 +554,7 @@ extern "C" int mdx_compute_forces(mdx_system *s, unsigned terms)
     if (terms & MDX_F_PME) if ((rc = mdx_launch_pme(s, true))) return rc;
     if ((rc = mdx_launch_bonded(s, true, terms))) return rc;
     if (terms & MDX_F_PULL) if ((rc = mdx_launch_pull(s, false, true))) return rc;
-    if (terms & MDX_F_NONBONDED) if ((rc = mdx_launch_nonbonded(s, true))) return rc;
+    if ((rc = mdx_launch_nonbonded(s, true, terms))) return rc;
     if ((rc = mdx_join(s))) return rc;
     if ((rc = mdx_launch_ke(s, true, true))) return rc;
     if ((rc = mdx_launch_ke(s, false, true))) return rc;
@@ -675,9 +675,9 @@ extern "C" int mdx_step(mdx_system *s, long long nsteps)
         if ((rc = mdx_launch_prepare(s))) return rc;
         if ((rc = mdx_fork(s))) return rc;
         // the nonbonded kernel is the critical path: enqueue it first, the side streams fill in
-        if ((rc = mdx_launch_nonbonded(s, need_vir))) return rc;
+        if ((rc = mdx_launch_nonbonded(s, need_vir, MDX_F_NONBONDED | (s->have_pme ? MDX_F_EXCL : 0)))) return rc;
         if ((rc = mdx_launch_pme(s, need_vir))) return rc;
-        if ((rc = mdx_launch_bonded(s, need_vir, MDX_F_BONDED | MDX_F_POSRES | (s->have_pme ? MDX_F_EXCL : 0)))) return rc;
+        if ((rc = mdx_launch_bonded(s, need_vir, MDX_F_BONDED | MDX_F_POSRES))) return rc;
         if (s->pull_on) {
             const bool log_now = (step % s->pull_nstout == 0);
             if ((rc = mdx_launch_pull(s, log_now, need_vir))) return rc;
@@ -764,7 +764,7 @@ extern "C" int mdx_debug_time_stage(mdx_system *s, int stage, int iters, double 
         switch (stage) {
         case 1: return mdx_search(s);
         case 2: case 6: return mdx_launch_pme(s, false);
-        case 3: return mdx_launch_bonded(s, false, MDX_F_BONDED | MDX_F_POSRES | MDX_F_EXCL);
+        case 3: return mdx_launch_bonded(s, false, MDX_F_BONDED | MDX_F_POSRES);
         case 4: { int r = mdx_launch_update(s, false, false, false); float4 *t = s->x; s->x = s->xp; s->xp = t; return r; }
         case 5: return mdx_launch_prepare(s);
         default: s->err = "mdx_debug_time_stage: unknown stage"; return MDX_ERR_ARG;

@@ -181,7 +181,7 @@ int mdx_search(mdx_system *s);
 int mdx_fork(mdx_system *s);
 int mdx_join(mdx_system *s);
 int mdx_launch_prepare(mdx_system *s);
-int mdx_launch_nonbonded(mdx_system *s, bool energy);
+int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms);
 int mdx_launch_pme(mdx_system *s, bool energy);
 int mdx_launch_bonded(mdx_system *s, bool energy, unsigned flags);
 int mdx_launch_pull(mdx_system *s, bool log_now, bool energy);

@@ -27,6 +27,8 @@ struct NbArgs {
     DevState *dw;
     float rc2, beta, c_rf_shift; // c_rf_shift = erfc(beta rc)/rc
     float inv_rc6;               // 1/rc^6
+    int central;                 // index of the zero lattice shift
+    int do_pairs, do_excl;       // evaluate listed pairs / the Ewald correction of excluded pairs
 };
 
 // Cross-lane adds inside groups of 8 consecutive lanes as DPP moves (no LDS crossbar traffic).
@@ -40,129 +42,6 @@ __device__ __forceinline__ float sum8(float v)
     v += dpp_quad_x2(v);
     v += dpp_half_mirror(v);
     return v;
-}
-
-template <bool ENERGY>
-__global__ __launch_bounds__(256) void k_nonbonded(NbArgs A)
-{
-    const int lane = threadIdx.x & 63;
-    const int ti = lane & 7, tj = lane >> 3;
-    const int nwork = A.d->nwork;
-    const int nwaves = gridDim.x * 4;
-    float elj = 0.0f, ecoul = 0.0f;
-    unsigned int npair = 0, nlj = 0;
-    float vxx = 0.0f, vxy = 0.0f, vxz = 0.0f, vyy = 0.0f, vyz = 0.0f, vzz = 0.0f;
-    const float rc2 = A.rc2, beta = A.beta;
-    const float nb2l2e = -beta * beta * 1.4426950408889634f; // exp(-b^2 r^2) = exp2(nb2l2e * r2)
-  for (int unit = blockIdx.x * 4 + (threadIdx.x >> 6); unit < nwork; unit += nwaves) {
-    const NbWork w = A.work[A.order[unit]];
-    const float4 S = A.shiftvec[w.shift & 0xFF];
-    float xi[8], yi[8], zi[8], qi[8], hsi[8], sei[8];
-    float fix[8], fiy[8], fiz[8];
-#pragma unroll
-    for (int c = 0; c < 8; c++) {
-        const int ia = (w.sci * 8 + c) * 8 + ti;
-        const float4 p = A.xq_s[ia];
-        const float2 l = A.lj_s[ia];
-        xi[c] = p.x - S.x; yi[c] = p.y - S.y; zi[c] = p.z - S.z;
-        qi[c] = p.w * MDX_ONE_4PI_EPS0;
-        hsi[c] = l.x; sei[c] = l.y;
-        fix[c] = 0.0f; fiy[c] = 0.0f; fiz[c] = 0.0f;
-    }
-
-    for (int e = w.cj_start; e < w.cj_end; e++) {
-        const NbEntry ent = A.cj[e];
-        const int cj = __builtin_amdgcn_readfirstlane(ent.cj);
-        const unsigned mk = __builtin_amdgcn_readfirstlane(ent.mask);
-        const unsigned imask = mk & 0xFFu;
-        const unsigned slot = mk >> 8;
-        const int ja = cj * 8 + tj;
-        const float4 pj = A.xq_s[ja];
-        const float2 lj = A.lj_s[ja];
-        unsigned ex = 0xFFu;
-        if (slot) ex = A.exclmask[(size_t)slot * 64 + lane];
-        float fjx = 0.0f, fjy = 0.0f, fjz = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-            if (imask & (1u << c)) {
-                const float dx = xi[c] - pj.x, dy = yi[c] - pj.y, dz = zi[c] - pj.z;
-                float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                const bool within = (r2 < rc2) && ((ex >> c) & 1u);
-                r2 = fmaxf(r2, 1.0e-12f);
-                const float rinv = __frsqrt_rn(r2);
-                const float rinv2 = rinv * rinv;
-                // Lennard-Jones
-                const float sg = hsi[c] + lj.x;
-                const float e4 = sei[c] * lj.y;
-                const float s2 = sg * sg * rinv2;
-                const float s6 = s2 * s2 * s2;
-                const float t6 = e4 * s6;
-                float fs = t6 * fmaf(12.0f, s6, -6.0f);
-                // Ewald real space
-                const float qq = qi[c] * pj.w;
-                const float br = beta * r2 * rinv;
-                const float ex2 = __builtin_amdgcn_exp2f(nb2l2e * r2);
-                const float erfc_br = ex2 * mdx_erfcx_poly(br);
-                const float cf = qq * rinv;
-                fs = fmaf(cf, fmaf(MDX_2_SQRTPI * br, ex2, erfc_br), fs);
-                fs *= rinv2;
-                fs = within ? fs : 0.0f;
-                const float fx = fs * dx, fy = fs * dy, fz = fs * dz;
-                fix[c] += fx; fiy[c] += fy; fiz[c] += fz;
-                fjx -= fx; fjy -= fy; fjz -= fz;
-                if (ENERGY) {
-                    if (within) {
-                        npair++;
-                        if (e4 != 0.0f) nlj++;
-                        const float c2 = sg * sg * (1.0f / rc2);
-                        const float c6 = c2 * c2 * c2;
-                        // t6 (s6 - 1) stays finite when e4 = 0 and s6 is huge (filler atoms)
-                        elj += t6 * (s6 - 1.0f) - e4 * c6 * (c6 - 1.0f);
-                        ecoul += qq * (erfc_br * rinv - A.c_rf_shift);
-                    }
-                    vxx = fmaf(dx, fx, vxx); vxy = fmaf(dx, fy, vxy); vxz = fmaf(dx, fz, vxz);
-                    vyy = fmaf(dy, fy, vyy); vyz = fmaf(dy, fz, vyz); vzz = fmaf(dz, fz, vzz);
-                }
-            }
-        }
-        // reduce the j force over the 8 lanes with equal tj (consecutive lanes)
-        fjx = sum8(fjx); fjy = sum8(fjy); fjz = sum8(fjz);
-        if (ti < 3) {
-            const float val = (ti == 0) ? fjx : ((ti == 1) ? fjy : fjz);
-            atomicAdd(&A.f_s[3 * ja + ti], val);
-        }
-    }
-    // reduce i forces over tj (lanes 8 apart) and add
-#pragma unroll
-    for (int c = 0; c < 8; c++) {
-        float ax = fix[c], ay = fiy[c], az = fiz[c];
-        ax += dpp_row_ror8(ax); ay += dpp_row_ror8(ay); az += dpp_row_ror8(az);
-        ax += __shfl_xor(ax, 16, 64); ay += __shfl_xor(ay, 16, 64); az += __shfl_xor(az, 16, 64);
-        ax += __shfl_xor(ax, 32, 64); ay += __shfl_xor(ay, 32, 64); az += __shfl_xor(az, 32, 64);
-        if (tj < 3) {
-            const float val = (tj == 0) ? ax : ((tj == 1) ? ay : az);
-            atomicAdd(&A.f_s[3 * ((w.sci * 8 + c) * 8 + ti) + tj], val);
-        }
-    }
-  }
-    if (ENERGY) {
-        elj = wave_sum(elj); ecoul = wave_sum(ecoul);
-        vxx = wave_sum(vxx); vxy = wave_sum(vxy); vxz = wave_sum(vxz);
-        vyy = wave_sum(vyy); vyz = wave_sum(vyz); vzz = wave_sum(vzz);
-        unsigned long long np64 = npair, nl64 = nlj;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { np64 += __shfl_xor(np64, o, 64); nl64 += __shfl_xor(nl64, o, 64); }
-        if (lane == 0) {
-            atomicAdd(&A.dw->npairs_rc, np64);
-            atomicAdd(&A.dw->npairs_lj, nl64);
-            atomicAdd(&A.dw->ener[MDX_E_LJ], (double)elj);
-            atomicAdd(&A.dw->ener[MDX_E_COUL_SR], (double)ecoul);
-            double *v = A.dw->vir;
-            atomicAdd(&v[0], -0.5 * vxx); atomicAdd(&v[1], -0.5 * vxy); atomicAdd(&v[2], -0.5 * vxz);
-            atomicAdd(&v[3], -0.5 * vxy); atomicAdd(&v[4], -0.5 * vyy); atomicAdd(&v[5], -0.5 * vyz);
-            atomicAdd(&v[6], -0.5 * vxz); atomicAdd(&v[7], -0.5 * vyz); atomicAdd(&v[8], -0.5 * vzz);
-        }
-    }
 }
 
 // g(w) = (erf(z)/z - 2/sqrt(pi) exp(-w))/w, w = z^2: rational fit of degree (5,5) on 0 <= w <= 16
@@ -190,14 +69,15 @@ __device__ __forceinline__ float mdx_pmecorr(float w)
 // evaluated, two j-clusters share one 48-lane float atomic, and the force-only variant replaces
 // exp + erfc by the rational Ewald correction above.
 template <bool ENERGY>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_v2(NbArgs A)
+__device__ __forceinline__ void nb_body(const NbArgs &A)
 {
     const int lane = threadIdx.x & 63;
     const int ti = lane & 7, tj = lane >> 3;
     const int nwork = A.d->nwork;
     const int nwaves = gridDim.x * 4;
-    float elj = 0.0f, ecoul = 0.0f;
+    float elj = 0.0f, ecoul = 0.0f, eexcl = 0.0f;
     unsigned int npair = 0, nlj = 0;
+    const bool do_pairs = A.do_pairs != 0, do_excl = A.do_excl != 0;
     float vxx = 0.0f, vxy = 0.0f, vxz = 0.0f, vyy = 0.0f, vyz = 0.0f, vzz = 0.0f;
     const float rc2 = A.rc2, beta = A.beta;
     const float beta2 = beta * beta, beta3 = beta2 * beta;
@@ -213,7 +93,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int sci = __builtin_amdgcn_readfirstlane(w.sci);
         const int e0 = __builtin_amdgcn_readfirstlane(w.cj_start);
         const int count = __builtin_amdgcn_readfirstlane(w.cj_end) - e0;
-        const float4 S = A.shiftvec[__builtin_amdgcn_readfirstlane(w.shift) & 0xFF];
+        const int shift_idx = __builtin_amdgcn_readfirstlane(w.shift) & 0xFF;
+        const bool is_central = shift_idx == A.central;
+        const float4 S = A.shiftvec[shift_idx];
         NbEntry myent; myent.cj = 0; myent.mask = 0;
         if (lane < count) myent = A.cj[e0 + lane];
         float xi[8], yi[8], zi[8], qi[8], hsi[8], sei[8];
@@ -246,13 +128,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const unsigned slot = mk >> 8;
             unsigned ex = 0xFFu;
             if (slot) ex = A.exclmask[(size_t)slot * 64 + lane];
+            // `live` bit c: this lane's pair with i-cluster c is evaluated at all. In the tile of a
+            // cluster with itself only tj > ti is (each pair once, no self pair); listed pairs need
+            // do_pairs, excluded pairs need do_excl.
+            unsigned live = do_pairs ? ex : 0u;
+            if (do_excl) live |= ~ex & 0xFFu;
+            if (is_central && (cj >> 3) == sci && tj <= ti) live &= ~(1u << (cj & 7));
             float fjx = 0.0f, fjy = 0.0f, fjz = 0.0f;
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 if (imask & (1u << c)) {
                     const float dx = xi[c] - pj.x, dy = yi[c] - pj.y, dz = zi[c] - pj.z;
                     float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                    const bool within = (r2 < rc2) && ((ex >> c) & 1u);
+                    const bool within = (r2 < rc2) && ((live >> c) & 1u);
+                    const bool listed = (ex >> c) & 1u;          // false: excluded pair, Ewald correction only
                     r2 = fmaxf(r2, 1.0e-12f);
                     const float rinv = __frsqrt_rn(r2);
                     const float rinv2 = rinv * rinv;
@@ -263,16 +152,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     const float t6 = e4 * s6;
                     float fs = t6 * fmaf(12.0f, s6, -6.0f);
                     const float qq = qi[c] * pj.w;
-                    float erfc_br = 0.0f;
+                    float erfc_br = 0.0f, e_ex = 0.0f;
                     if (ENERGY) {
                         const float br = beta * r2 * rinv;
                         const float ex2 = __builtin_amdgcn_exp2f(nb2l2e * r2);
                         erfc_br = ex2 * mdx_erfcx_poly(br);
                         fs = fmaf(qq * rinv, fmaf(MDX_2_SQRTPI * br, ex2, erfc_br), fs);
                         fs *= rinv2;
+                        if (slot) {
+                            // tiles that hold excluded pairs (wave-uniform test): E = -qq erf(br)/r through the
+                            // cancellation-free g: erf(z)/z = g w + 2/sqrt(pi) exp(-w)
+                            const float w_ = beta2 * r2;
+                            const float g = mdx_pmecorr(w_);
+                            fs = listed ? fs : -qq * beta3 * g;
+                            e_ex = -qq * beta * fmaf(g, w_, MDX_2_SQRTPI * ex2);
+                        }
                     } else {
-                        // (t6 (12 s6 - 6) + qq/r) / r^2 - qq beta^3 g
+                        // (t6 (12 s6 - 6) + qq/r) / r^2 - qq beta^3 g; an excluded pair keeps only the last term
                         fs = fmaf(qq, rinv, fs) * rinv2;
+                        if (slot) fs = listed ? fs : 0.0f;      // wave-uniform: most tiles hold no excluded pair
                         fs = fmaf(-qq * beta3, mdx_pmecorr(beta2 * r2), fs);
                     }
                     fs = within ? fs : 0.0f;
@@ -280,13 +178,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     fix[c] += fx; fiy[c] += fy; fiz[c] += fz;
                     fjx -= fx; fjy -= fy; fjz -= fz;
                     if (ENERGY) {
-                        if (within) {
+                        if (within && listed) {
                             npair++;
                             if (e4 != 0.0f) nlj++;
                             const float c2 = sg * sg * (1.0f / rc2);
                             const float c6 = c2 * c2 * c2;
                             elj += t6 * (s6 - 1.0f) - e4 * c6 * (c6 - 1.0f);
                             ecoul += qq * (erfc_br * rinv - A.c_rf_shift);
+                        } else if (within) {
+                            eexcl += e_ex;
                         }
                         vxx = fmaf(dx, fx, vxx); vxy = fmaf(dx, fy, vxy); vxz = fmaf(dx, fz, vxz);
                         vyy = fmaf(dy, fy, vyy); vyz = fmaf(dy, fz, vyz); vzz = fmaf(dz, fz, vzz);
@@ -321,7 +221,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
     }
     if (ENERGY) {
-        elj = wave_sum(elj); ecoul = wave_sum(ecoul);
+        elj = wave_sum(elj); ecoul = wave_sum(ecoul); eexcl = wave_sum(eexcl);
         vxx = wave_sum(vxx); vxy = wave_sum(vxy); vxz = wave_sum(vxz);
         vyy = wave_sum(vyy); vyz = wave_sum(vyz); vzz = wave_sum(vzz);
         unsigned long long np64 = npair, nl64 = nlj;
@@ -332,6 +232,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             atomicAdd(&A.dw->npairs_lj, nl64);
             atomicAdd(&A.dw->ener[MDX_E_LJ], (double)elj);
             atomicAdd(&A.dw->ener[MDX_E_COUL_SR], (double)ecoul);
+            atomicAdd(&A.dw->ener[MDX_E_COUL_EXCL], (double)eexcl);
             double *v = A.dw->vir;
             atomicAdd(&v[0], -0.5 * vxx); atomicAdd(&v[1], -0.5 * vxy); atomicAdd(&v[2], -0.5 * vxz);
             atomicAdd(&v[3], -0.5 * vxy); atomicAdd(&v[4], -0.5 * vyy); atomicAdd(&v[5], -0.5 * vyz);
@@ -340,9 +241,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
-int mdx_launch_nonbonded(mdx_system *s, bool energy)
+// Force-only steps: 4 waves per SIMD (<= 128 VGPRs). Energy/virial steps carry the extra
+// accumulators and the erfc evaluation: 3 waves per SIMD (<= 168 VGPRs) instead of spilling.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_f(NbArgs A) { nb_body<false>(A); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_ev(NbArgs A) { nb_body<true>(A); }
+
+int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
 {
     NbArgs A;
+    A.central = s->central_shift;
+    A.do_pairs = (terms & MDX_F_NONBONDED) ? 1 : 0;
+    A.do_excl = ((terms & MDX_F_EXCL) && s->beta > 0.0f) ? 1 : 0;
+    if (!A.do_pairs && !A.do_excl) return MDX_OK;
     A.d = s->d; A.dw = s->d; A.work = s->work; A.order = s->work_order; A.cj = s->cj; A.exclmask = s->exclmask; A.xq_s = s->xq_s; A.lj_s = s->lj_s;
     A.shiftvec = s->shiftvec; A.f_s = s->f_s;
     A.rc2 = s->rc * s->rc; A.beta = s->beta;
@@ -350,7 +260,7 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy)
     A.inv_rc6 = 1.0f / (A.rc2 * A.rc2 * A.rc2);
     // grid-stride over work units: the unit count lives in device memory, so the grid is fixed
     // (4 blocks of 4 waves per CU) and every wave exits once the list is exhausted
-    const int nblk = 1024;
+    const int nblk = energy ? 768 : 1024;     // resident waves only: 3 resp. 4 blocks of 4 waves per CU
     int e0 = -1, e1 = -1;
     if (s->time_nb) {
         hipEvent_t a, b;
@@ -359,14 +269,8 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy)
         e0 = (int)s->ev_pool.size() - 2; e1 = e0 + 1;
         MDX_CHECK(s, hipEventRecord(s->ev_pool[e0], s->stream));
     }
-    const int variant = s->nb_variant;
-    if (variant == 1) {
-        if (energy) hipLaunchKernelGGL(k_nonbonded<true>, dim3(nblk), dim3(256), 0, s->stream, A);
-        else hipLaunchKernelGGL(k_nonbonded<false>, dim3(nblk), dim3(256), 0, s->stream, A);
-    } else {
-        if (energy) hipLaunchKernelGGL(k_nonbonded_v2<true>, dim3(nblk), dim3(256), 0, s->stream, A);
-        else hipLaunchKernelGGL(k_nonbonded_v2<false>, dim3(nblk), dim3(256), 0, s->stream, A);
-    }
+    if (energy) hipLaunchKernelGGL(k_nonbonded_ev, dim3(nblk), dim3(256), 0, s->stream, A);
+    else hipLaunchKernelGGL(k_nonbonded_f, dim3(nblk), dim3(256), 0, s->stream, A);
     MDX_CHECK(s, hipGetLastError());
     if (s->time_nb) {
         MDX_CHECK(s, hipEventRecord(s->ev_pool[e1], s->stream));
@@ -384,11 +288,11 @@ extern "C" int mdx_debug_time_nonbonded(mdx_system *s, int energy, int iters, do
     MDX_CHECK(s, hipEventCreate(&a)); MDX_CHECK(s, hipEventCreate(&b));
     const bool keep = s->time_nb; s->time_nb = false;
     (void)hipMemsetAsync((char *)s->d + offsetof(DevState, work_head), 0, sizeof(int) * 8, s->stream);
-    int rc = mdx_launch_nonbonded(s, energy != 0);          // warm
+    int rc = mdx_launch_nonbonded(s, energy != 0, MDX_F_NONBONDED | MDX_F_EXCL);          // warm
     MDX_CHECK(s, hipEventRecord(a, s->stream));
     for (int i = 0; i < iters && rc == MDX_OK; i++) {
         (void)hipMemsetAsync((char *)s->d + offsetof(DevState, work_head), 0, sizeof(int) * 8, s->stream);
-        rc = mdx_launch_nonbonded(s, energy != 0);
+        rc = mdx_launch_nonbonded(s, energy != 0, MDX_F_NONBONDED | MDX_F_EXCL);
     }
     MDX_CHECK(s, hipEventRecord(b, s->stream));
     MDX_CHECK(s, hipEventSynchronize(b));
@@ -402,7 +306,7 @@ extern "C" int mdx_debug_time_nonbonded(mdx_system *s, int energy, int iters, do
 
 extern "C" int mdx_debug_set(mdx_system *s, int key, int value)
 {
-    if (key == 1) { s->nb_variant = value; return MDX_OK; }
+    if (key == 1) return MDX_OK;      // kernel-variant selector of earlier builds: one kernel now
     if (key == 2) { s->dbg = value; return MDX_OK; }
     s->err = "mdx_debug_set: unknown key"; return MDX_ERR_ARG;
 }

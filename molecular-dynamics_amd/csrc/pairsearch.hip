@@ -316,9 +316,10 @@ __global__ __launch_bounds__(256) void k_build_list(ListArgs A)
                                 const float4 xi = xi_sh[ci * 8 + ti];
                                 const float dx = xi.x - S.x - xj.x, dy = xi.y - S.y - xj.y, dz = xi.z - S.z - xj.z;
                                 const bool in = (dx * dx + dy * dy + dz * dz) < rl2;
+                                // bit cleared = topologically excluded pair (the nonbonded kernel gives those the
+                                // Ewald correction and itself skips the lower half of a cluster's tile with itself)
                                 bool ex = false;
-                                if (central && cjg == sci * 8 + ci) ex = (tj <= ti);   // same cluster: each pair once
-                                if (!ex && molj >= 0 && mol_sh[ci * 8 + ti] == molj) {
+                                if (molj >= 0 && mol_sh[ci * 8 + ti] == molj && !(central && cjg == sci * 8 + ci && tj == ti)) {
                                     const int oi = orig_sh[ci * 8 + ti];
                                     const int e0 = A.excl_start[oi], e1 = A.excl_start[oi + 1];
                                     for (int k = e0; k < e1; k++)
