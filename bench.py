@@ -111,6 +111,8 @@ def main():
     e = engine_for(s, args, "relax", seed, local); e.step(args.prep_steps); s1 = carry(s, e); e.close()
     e = engine_for(s1, args, "equil", seed, local); e.step(args.prep_steps); s2 = carry(s1, e); e.close()
     e = engine_for(s2, args, "run", seed, local)
+    if os.environ.get("MDX_NB_VARIANT"):      # diagnostic A/B of nonbonded launch shapes
+        e.debug_set(1, int(os.environ["MDX_NB_VARIANT"]))
     dt = e.dt
     # ---- warmup
     e.step(args.warmup); e.synchronize()

@@ -58,8 +58,14 @@ extern "C" mdx_system *mdx_create(int device, int natoms)
     if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return nullptr; }
     mdx_system *s = new mdx_system();
     s->device = device; s->n = natoms;
-    bool ok = hipStreamCreate(&s->stream) == hipSuccess && hipStreamCreate(&s->st_pme) == hipSuccess &&
-              hipStreamCreate(&s->st_bond) == hipSuccess && hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) == hipSuccess &&
+    // the side streams get the highest priority so that their small kernels take wave slots as soon
+    // as the wide nonbonded grid on the main stream frees any
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    bool ok = hipStreamCreate(&s->stream) == hipSuccess &&
+              hipStreamCreateWithPriority(&s->st_pme, hipStreamDefault, prio_greatest) == hipSuccess &&
+              hipStreamCreateWithPriority(&s->st_bond, hipStreamDefault, prio_greatest) == hipSuccess &&
+              hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_pme, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_bond, hipEventDisableTiming) == hipSuccess;
     const int n = natoms;

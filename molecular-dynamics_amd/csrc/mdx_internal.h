@@ -63,7 +63,7 @@ struct mdx_system {
     long long pull_log_popped = 0;
     bool pull_reset_pending = false;
     int dbg = 0;                       // diagnostic ablation bits (mdx_debug_set key 2)
-    int nb_variant = 2;                // 1: first-generation kernel, 2: prefetching kernel with rational Ewald correction
+    int nb_variant = 33;               // nonbonded launch shape: 10 * waves/SIMD of the energy kernel + waves/SIMD of the force kernel
     hipStream_t stream = nullptr;      // main stream: search, nonbonded, update
     hipStream_t st_pme = nullptr;      // PME chain (spread, FFTs, solve, gather) overlaps the nonbonded kernel
     hipStream_t st_bond = nullptr;     // bonded, restraint, exclusion and pull kernels

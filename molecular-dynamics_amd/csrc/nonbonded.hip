@@ -245,6 +245,11 @@ __device__ __forceinline__ void nb_body(const NbArgs &A)
 // accumulators and the erfc evaluation: 3 waves per SIMD (<= 168 VGPRs) instead of spilling.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_f(NbArgs A) { nb_body<false>(A); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_ev(NbArgs A) { nb_body<true>(A); }
+// Variant that leaves a quarter of each SIMD's wave slots and registers to the kernels of the
+// PME and bonded streams (selected with mdx_debug_set key 1 = 3).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3(NbArgs A) { nb_body<false>(A); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_nonbonded_f2(NbArgs A) { nb_body<false>(A); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_nonbonded_ev2(NbArgs A) { nb_body<true>(A); }
 
 int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
 {
@@ -260,7 +265,10 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
     A.inv_rc6 = 1.0f / (A.rc2 * A.rc2 * A.rc2);
     // grid-stride over work units: the unit count lives in device memory, so the grid is fixed
     // (4 blocks of 4 waves per CU) and every wave exits once the list is exhausted
-    const int nblk = energy ? 768 : 1024;     // resident waves only: 3 resp. 4 blocks of 4 waves per CU
+    // resident waves only: `wv` blocks of 4 waves per CU. nb_variant = 10 * (energy-kernel waves) + force-kernel waves
+    int wv = energy ? s->nb_variant / 10 : s->nb_variant % 10;
+    if (wv < 2 || wv > 4 || (energy && wv == 4)) wv = 3;
+    const int nblk = 256 * wv;
     int e0 = -1, e1 = -1;
     if (s->time_nb) {
         hipEvent_t a, b;
@@ -269,7 +277,10 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
         e0 = (int)s->ev_pool.size() - 2; e1 = e0 + 1;
         MDX_CHECK(s, hipEventRecord(s->ev_pool[e0], s->stream));
     }
-    if (energy) hipLaunchKernelGGL(k_nonbonded_ev, dim3(nblk), dim3(256), 0, s->stream, A);
+    if (energy && wv == 2) hipLaunchKernelGGL(k_nonbonded_ev2, dim3(nblk), dim3(256), 0, s->stream, A);
+    else if (energy) hipLaunchKernelGGL(k_nonbonded_ev, dim3(nblk), dim3(256), 0, s->stream, A);
+    else if (wv == 2) hipLaunchKernelGGL(k_nonbonded_f2, dim3(nblk), dim3(256), 0, s->stream, A);
+    else if (wv == 3) hipLaunchKernelGGL(k_nonbonded_f3, dim3(nblk), dim3(256), 0, s->stream, A);
     else hipLaunchKernelGGL(k_nonbonded_f, dim3(nblk), dim3(256), 0, s->stream, A);
     MDX_CHECK(s, hipGetLastError());
     if (s->time_nb) {
@@ -306,7 +317,7 @@ extern "C" int mdx_debug_time_nonbonded(mdx_system *s, int energy, int iters, do
 
 extern "C" int mdx_debug_set(mdx_system *s, int key, int value)
 {
-    if (key == 1) return MDX_OK;      // kernel-variant selector of earlier builds: one kernel now
+    if (key == 1) { s->nb_variant = value; return MDX_OK; }
     if (key == 2) { s->dbg = value; return MDX_OK; }
     s->err = "mdx_debug_set: unknown key"; return MDX_ERR_ARG;
 }
