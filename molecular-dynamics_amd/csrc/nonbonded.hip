@@ -141,6 +141,9 @@ __device__ __forceinline__ void nb_body(const NbArgs &A)
                     const float dx = xi[c] - pj.x, dy = yi[c] - pj.y, dz = zi[c] - pj.z;
                     float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
                     const bool within = (r2 < rc2) && ((live >> c) & 1u);
+                    // the list is built with a buffer: an 8x8 tile none of whose pairs is inside the
+                    // cutoff right now costs only the distance test (wave-uniform skip)
+                    if (__builtin_amdgcn_ballot_w64(within) == 0ull) continue;
                     const bool listed = (ex >> c) & 1u;          // false: excluded pair, Ewald correction only
                     r2 = fmaxf(r2, 1.0e-12f);
                     const float rinv = __frsqrt_rn(r2);

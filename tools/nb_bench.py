@@ -1,29 +1,31 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of the nonbonded kernel variants on one pair list (interleaved rounds, one process)."""
+"""Nonbonded launch-shape A/B: alone-time of the force kernel per variant on the S2 list and a
+one-step consistency check of every variant against the default one.
+Variant = 10 * (waves/SIMD of the energy kernel) + force-kernel digit (2-4 scalar body at that
+many waves/SIMD, 7 / 8 packed-math body at 3 / 4 waves/SIMD)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, mdx
 from mdx import synth, engine as eng
-from oracle import mdref as R
-s = synth.water_box(d=12.5)
-e = eng.Engine(s, rc=1.0, nstcalcenergy=100, tc_groups=["System"], ref_t=[300.0], tau_t=[0.1])
-e.step(300); e.synchronize()
-f, en = e.compute(eng.F_NONBONDED)
-st = e.list_stats(); print(st)
-flops = 66.0 * st["pairs_with_lj"] + 54.0 * (st["pairs_within_rc"] - st["pairs_with_lj"])
-res = {1: [], 2: []}
-for rnd in range(5):
-    for v in (1, 2):
+
+variants = [int(a) for a in sys.argv[1:]] or [33, 34, 37, 38]
+s = synth.pseudo_complex(d=6.0, protein_radius=1.0, n_active=60, ligand_offset=1.2)
+ref = None
+for v in variants:
+    e = eng.Engine(s, rc=1.0, nstcalcenergy=0, nstlist=10)
+    e.debug_set(1, v)
+    e.step(3)
+    x, vel, _ = e.get_state()
+    e.close()
+    if ref is None:
+        ref = (x, vel)
+    print("variant %d: 3 steps, max |dx| vs first variant %.2e nm, max |dv| %.2e nm/ps" % (v, np.abs(x - ref[0]).max(), np.abs(vel - ref[1]).max()))
+
+s = synth.pseudo_complex(d=12.5)
+tc = ["Protein", "Non-Protein"]
+e = eng.Engine(s, rc=1.0, dt=0.0005, nstlist=20, nstcalcenergy=0, tc_groups=tc, ref_t=[300, 300], tau_t=[0.02, 0.02], nsttcouple=2)
+e.step(1500); e.synchronize()
+for rep in range(2):
+    for v in variants:
         e.debug_set(1, v)
-        res[v].append(e.debug_time_nonbonded(False, 40))
-for v in (1, 2):
-    t = np.array(res[v]); print(f"variant {v}: median {np.median(t)*1e3:.1f} us  min {t.min()*1e3:.1f} us  -> {flops/np.median(t)/1e9:.2f} TFLOP/s algorithmic")
-# parity of each variant on a smaller box
-s2 = synth.water_box(d=4.0); s2.x = s2.x.astype(np.float32).astype(np.float64)
-e2 = eng.Engine(s2, rc=1.0, nstcalcenergy=1)
-o = R.nonbonded(s2.x, s2.charge, s2.sigma, s2.eps, s2.box, 1.0, e2.beta, s2.excl_start, s2.excl_list, flags=1, nthreads=8)
-for v in (1, 2):
-    e2.debug_set(1, v)
-    f, en = e2.compute(eng.F_NONBONDED)
-    print(f"variant {v} energy-kernel force relrms {np.sqrt(((f-o['f'])**2).sum()/(o['f']**2).sum()):.3e}")
-    # force-only kernel: one step of dynamics uses it; compare via a zero-velocity single step displacement
+        print("variant %d: force kernel alone %.1f us" % (v, e.debug_time_nonbonded(False, 40) * 1e3))
