@@ -17,14 +17,14 @@ __device__ void accum_ev(double e, const float *v9, DevState *dw, int eidx, doub
 {
     __shared__ double red[16];
     double r = block_sum_d(e, red);
-    if (threadIdx.x == 0 && r != 0.0) atomicAdd(&dw->ener[eidx], r);
+    if (threadIdx.x == 0 && r != 0.0) atomicAdd(&MDX_ENER(dw, eidx), r);
     if (eidx2 >= 0) {
         r = block_sum_d(e2, red);
-        if (threadIdx.x == 0 && r != 0.0) atomicAdd(&dw->ener[eidx2], r);
+        if (threadIdx.x == 0 && r != 0.0) atomicAdd(&MDX_ENER(dw, eidx2), r);
     }
     for (int k = 0; k < 9; k++) {
         r = block_sum_d((double)v9[k], red);
-        if (threadIdx.x == 0 && r != 0.0) atomicAdd(&dw->vir[k], -0.5 * r);
+        if (threadIdx.x == 0 && r != 0.0) atomicAdd(&MDX_VIR(dw, k), -0.5 * r);
     }
 }
 

@@ -295,7 +295,13 @@ extern "C" int mdx_set_constraints(mdx_system *s, int n, const int *idx, const f
     std::iota(order_idx.begin(), order_idx.end(), 0);
     std::vector<int> root(n);
     for (int k = 0; k < n; k++) root[k] = find(k);
-    std::stable_sort(order_idx.begin(), order_idx.end(), [&](int a, int b) { return root[a] < root[b]; });
+    // components by ascending size (then by root) so that the small ones form a contiguous front
+    std::vector<int> csize(n, 0);
+    for (int k = 0; k < n; k++) csize[root[k]]++;
+    std::stable_sort(order_idx.begin(), order_idx.end(), [&](int a, int b) {
+        const int sa = csize[root[a]], sb = csize[root[b]];
+        return sa != sb ? sa < sb : root[a] < root[b];
+    });
     std::vector<int2> cij(n); std::vector<float> cl(n); std::vector<int> cstart;
     for (int k = 0; k < n; k++) {
         const int c = order_idx[k];
@@ -309,6 +315,8 @@ extern "C" int mdx_set_constraints(mdx_system *s, int n, const int *idx, const f
             return MDX_ERR_UNSUPPORTED;
         }
     s->ncons = n; s->ncomp = n ? (int)cstart.size() - 1 : 0; s->lincs_order = order; s->lincs_iter = iter;
+    s->ncomp_small = 0;
+    for (int c = 0; c < s->ncomp; c++) if (cstart[c + 1] - cstart[c] <= 4) s->ncomp_small = c + 1;
     rc = dev_upload(s, &s->cons_ij, cij); if (rc) return rc;
     rc = dev_upload(s, &s->cons_len, cl); if (rc) return rc;
     return dev_upload(s, &s->comp_start, cstart);
@@ -566,6 +574,7 @@ extern "C" int mdx_compute_forces(mdx_system *s, unsigned terms)
     if ((rc = mdx_launch_ke(s, false, true))) return rc;
     if ((rc = mdx_launch_finish_energy(s))) return rc;
     s->forces_current = true;
+    s->f_dirty = true;
     return sync_and_check(s);
 }
 
@@ -676,7 +685,8 @@ extern "C" int mdx_step(mdx_system *s, long long nsteps)
             if ((rc = mdx_launch_clear(s, true, true, true))) return rc;
             if ((rc = mdx_launch_ke(s, true, true))) return rc;
         }
-        MDX_CHECK(s, hipMemsetAsync(s->f, 0, sizeof(float) * 3 * s->n, s->stream));
+        // the leap-frog kernel leaves f cleared; only a force evaluation outside the step loop dirties it
+        if (s->f_dirty) { MDX_CHECK(s, hipMemsetAsync(s->f, 0, sizeof(float) * 3 * s->n, s->stream)); s->f_dirty = false; }
         if (do_search) if ((rc = mdx_search(s))) return rc;
         if ((rc = mdx_launch_prepare(s))) return rc;
         if ((rc = mdx_fork(s))) return rc;
@@ -785,6 +795,7 @@ extern "C" int mdx_debug_time_stage(mdx_system *s, int stage, int iters, double 
     MDX_CHECK(s, hipEventElapsedTime(&ms, a, b));
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     s->dbg = saved;
+    s->f_dirty = true;
     MDX_CHECK(s, hipDeviceSynchronize());
     if (avg_ms) *avg_ms = ms / (iters > 0 ? iters : 1);
     return rc;

@@ -49,7 +49,21 @@ struct DevState {
     // pair counters of the last energy step: non-excluded pairs with r < rc, and those with LJ
     unsigned long long npairs_rc, npairs_lj;
     int work_head[8];             // per-queue dequeue counters of the nonbonded kernel (cleared every step)
+    // Replicated accumulators of the energy steps: thousands of workgroups adding doubles to one
+    // address serialise in L2, so each adds to replica (block index mod MDX_NREP) and
+    // k_finish_energy folds the replicas into ener / vir / ekin_tensor / npairs.
+    double ener_rep[64][MDX_E_N];
+    double vir_rep[64][9];
+    double ekt_rep[64][9];
+    unsigned long long npairs_rep[64][2];
 };
+#define MDX_NREP 64
+#ifdef __HIPCC__
+__device__ __forceinline__ int mdx_rep() { return (int)((blockIdx.x + 5u * blockIdx.y) & (MDX_NREP - 1)); }
+#define MDX_ENER(dw, t) ((dw)->ener_rep[mdx_rep()][t])
+#define MDX_VIR(dw, k) ((dw)->vir_rep[mdx_rep()][k])
+#define MDX_EKT(dw, k) ((dw)->ekt_rep[mdx_rep()][k])
+#endif
 
 struct NbEntry { int cj; unsigned int mask; };        // mask: bits 0-7 i-cluster mask, bits 8.. exclusion slot
 struct NbWork { int sci; int shift; int cj_start; int cj_end; };
@@ -127,7 +141,7 @@ struct mdx_system {
     int refcoord_scaling = 0;     // 0 no, 1 all, 2 com
     // constraints
     int nsettle = 0; int4 *settle_idx = nullptr; float settle_doh = 0, settle_dhh = 0;
-    int ncons = 0; int ncomp = 0;
+    int ncons = 0; int ncomp = 0; int ncomp_small = 0;   // components are sorted by size; the first ncomp_small have <= 4 constraints
     int2 *cons_ij = nullptr; float *cons_len = nullptr; int *comp_start = nullptr;  // constraints sorted by component
     int lincs_order = 4, lincs_iter = 1;
     // integration / coupling
@@ -158,6 +172,7 @@ struct mdx_system {
     long long steps_since_search = 1 << 30;
     bool first_step = true;
     bool forces_current = false;
+    bool f_dirty = true;          // f holds something other than zeros at the start of the next step
     // energy history ring (pinned)
     double *ener_log = nullptr; int ener_log_cap = 0; long long ener_log_count = 0;
     // timing of the dominant kernel (HIP events on this stream)

@@ -231,12 +231,14 @@ __device__ __forceinline__ void nb_body(const NbArgs &A)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { np64 += __shfl_xor(np64, o, 64); nl64 += __shfl_xor(nl64, o, 64); }
         if (lane == 0) {
-            atomicAdd(&A.dw->npairs_rc, np64);
-            atomicAdd(&A.dw->npairs_lj, nl64);
-            atomicAdd(&A.dw->ener[MDX_E_LJ], (double)elj);
-            atomicAdd(&A.dw->ener[MDX_E_COUL_SR], (double)ecoul);
-            atomicAdd(&A.dw->ener[MDX_E_COUL_EXCL], (double)eexcl);
-            double *v = A.dw->vir;
+            // replicated accumulators (folded by the finishing kernel): one replica per wave index mod 64
+            const int rep = wave_id & (MDX_NREP - 1);
+            atomicAdd(&A.dw->npairs_rep[rep][0], np64);
+            atomicAdd(&A.dw->npairs_rep[rep][1], nl64);
+            atomicAdd(&A.dw->ener_rep[rep][MDX_E_LJ], (double)elj);
+            atomicAdd(&A.dw->ener_rep[rep][MDX_E_COUL_SR], (double)ecoul);
+            atomicAdd(&A.dw->ener_rep[rep][MDX_E_COUL_EXCL], (double)eexcl);
+            double *v = A.dw->vir_rep[rep];
             atomicAdd(&v[0], -0.5 * vxx); atomicAdd(&v[1], -0.5 * vxy); atomicAdd(&v[2], -0.5 * vxz);
             atomicAdd(&v[3], -0.5 * vxy); atomicAdd(&v[4], -0.5 * vyy); atomicAdd(&v[5], -0.5 * vyz);
             atomicAdd(&v[6], -0.5 * vxz); atomicAdd(&v[7], -0.5 * vyz); atomicAdd(&v[8], -0.5 * vzz);

@@ -187,13 +187,13 @@ __global__ __launch_bounds__(256) void k_pme_solve(float2 *__restrict__ cgrid, c
     }
     if (ENERGY) {
         double r = block_sum_d(e, red);
-        if (threadIdx.x == 0) atomicAdd(&dw->ener[MDX_E_COUL_RECIP], r);
+        if (threadIdx.x == 0) atomicAdd(&MDX_ENER(dw, MDX_E_COUL_RECIP), r);
         const int map[6][2] = { { 0, 0 }, { 1, 3 }, { 2, 6 }, { 4, 4 }, { 5, 7 }, { 8, 8 } };
         for (int k = 0; k < 6; k++) {
             r = block_sum_d(v[k], red);
             if (threadIdx.x == 0) {
-                atomicAdd(&dw->vir[map[k][0]], -0.5 * r);
-                if (map[k][1] != map[k][0]) atomicAdd(&dw->vir[map[k][1]], -0.5 * r);
+                atomicAdd(&MDX_VIR(dw, map[k][0]), -0.5 * r);
+                if (map[k][1] != map[k][0]) atomicAdd(&MDX_VIR(dw, map[k][1]), -0.5 * r);
             }
         }
     }

@@ -9,7 +9,7 @@
 // v' = lambda_g * (v + f/m dt) - dt * M v  (M: Parrinello-Rahman coupling matrix, zero otherwise);
 // xp = x + v' dt. Total force = original-order array + sorted nonbonded buffer.
 __global__ __launch_bounds__(256) void k_leapfrog(int n, const float4 *__restrict__ x, float4 *__restrict__ xp,
-                                                  float4 *__restrict__ v, const float *__restrict__ f, const float *__restrict__ f_pme,
+                                                  float4 *__restrict__ v, float *__restrict__ f, const float *__restrict__ f_pme,
                                                   const float *__restrict__ f_s, const int *__restrict__ sorted_of,
                                                   const int *__restrict__ tcgrp, const DevState *__restrict__ d, float dt,
                                                   int use_lambda, int use_pr)
@@ -21,6 +21,9 @@ __global__ __launch_bounds__(256) void k_leapfrog(int n, const float4 *__restric
     const int g = sorted_of[i];
     const float fx = f[3 * i] + f_pme[3 * i] + f_s[3 * g], fy = f[3 * i + 1] + f_pme[3 * i + 1] + f_s[3 * g + 1],
                 fz = f[3 * i + 2] + f_pme[3 * i + 2] + f_s[3 * g + 2];
+    // the accumulation buffer of the bonded-type kernels is consumed here: leave it cleared for the
+    // next step instead of paying a separate fill on the critical path
+    f[3 * i] = 0.0f; f[3 * i + 1] = 0.0f; f[3 * i + 2] = 0.0f;
     const float im = vi.w;
     float lam = 1.0f;
     if (use_lambda) lam = (float)d->lambda[tcgrp[i]];
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256) void k_settle(int nw, const int4 *__restrict__
         __shared__ double red[16];
         for (int k = 0; k < 9; k++) {
             const double r = block_sum_d((double)v9[k], red);
-            if (threadIdx.x == 0) atomicAdd(&dw->vir[k], -0.5 * r);
+            if (threadIdx.x == 0) atomicAdd(&MDX_VIR(dw, k), -0.5 * r);
         }
     }
 }
@@ -122,22 +125,26 @@ __global__ __launch_bounds__(256) void k_settle(int nw, const int4 *__restrict__
 // LINCS (Hess et al. 1997) for small coupled components (h-bond constraints couple only through a
 // shared heavy atom): one thread per connected component of at most MDX_LINCS_MAXK constraints,
 // matrix expansion of order `order`, `niter` correction iterations for rotational lengthening.
-template <bool VIRIAL>
-__global__ __launch_bounds__(128) void k_lincs(int ncomp, const int *__restrict__ comp_start, const int2 *__restrict__ cij,
+// Components are stored by ascending size. Those of at most 4 constraints (CH, CH2, CH3, NH3
+// groups: nearly all of an h-bonds topology) run in the MAXK = 4 instantiation, whose loops have
+// constant bounds so that the per-component arrays live in registers; the rest use MAXK = 16.
+#define LINCS_FOR(k) _Pragma("unroll") for (int k = 0; k < (MAXK <= 4 ? MAXK : K); k++) if (MAXK > 4 || k < K)
+template <bool VIRIAL, int MAXK>
+__global__ __launch_bounds__(128) void k_lincs(int comp0, int ncomp, const int *__restrict__ comp_start, const int2 *__restrict__ cij,
                                                const float *__restrict__ clen, const float4 *__restrict__ x, float4 *__restrict__ xp,
                                                float4 *__restrict__ v, int order, int niter, float inv_dt, DevState *dw)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = comp0 + blockIdx.x * blockDim.x + threadIdx.x;
     float v9[9] = { 0 };
-    if (t < ncomp) {
+    if (t < comp0 + ncomp) {
         const int c0 = comp_start[t];
         const int K = comp_start[t + 1] - c0;
-        int ia[MDX_LINCS_MAXK], ib[MDX_LINCS_MAXK];
-        float3 B[MDX_LINCS_MAXK];
-        float S[MDX_LINCS_MAXK], len[MDX_LINCS_MAXK], rhs[MDX_LINCS_MAXK], sol[MDX_LINCS_MAXK], tmp[MDX_LINCS_MAXK];
-        float ima[MDX_LINCS_MAXK], imb[MDX_LINCS_MAXK], lamtot[MDX_LINCS_MAXK];
-        float Acoef[MDX_LINCS_MAXK][MDX_LINCS_MAXK];
-        for (int k = 0; k < K; k++) {
+        int ia[MAXK], ib[MAXK];
+        float3 B[MAXK];
+        float S[MAXK], len[MAXK], rhs[MAXK], sol[MAXK], tmp[MAXK];
+        float ima[MAXK], imb[MAXK], lamtot[MAXK];
+        float Acoef[MAXK][MAXK];
+        LINCS_FOR(k) {
             const int2 p = cij[c0 + k];
             ia[k] = p.x; ib[k] = p.y; len[k] = clen[c0 + k];
             ima[k] = v[p.x].w; imb[k] = v[p.y].w;
@@ -146,8 +153,8 @@ __global__ __launch_bounds__(128) void k_lincs(int ncomp, const int *__restrict_
             B[k] = rsqrtf(dot3(d, d)) * d;
             lamtot[k] = 0.0f;
         }
-        for (int k = 0; k < K; k++)
-            for (int m = 0; m < K; m++) {
+        LINCS_FOR(k)
+            LINCS_FOR(m) {
                 float c = 0.0f;
                 if (m != k) {
                     // sign +1 when the shared atom is first in both or second in both
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(128) void k_lincs(int ncomp, const int *__restrict_
                 Acoef[k][m] = c;
             }
         for (int pass = 0; pass <= niter; pass++) {
-            for (int k = 0; k < K; k++) {
+            LINCS_FOR(k) {
                 const float3 d = xyz(xp[ia[k]]) - xyz(xp[ib[k]]);
                 if (pass == 0) rhs[k] = S[k] * (dot3(B[k], d) - len[k]);
                 else {
@@ -170,14 +177,14 @@ __global__ __launch_bounds__(128) void k_lincs(int ncomp, const int *__restrict_
                 sol[k] = rhs[k];
             }
             for (int o = 0; o < order; o++) {
-                for (int k = 0; k < K; k++) {
+                LINCS_FOR(k) {
                     float a = 0.0f;
-                    for (int m = 0; m < K; m++) a += Acoef[k][m] * rhs[m];
+                    LINCS_FOR(m) a += Acoef[k][m] * rhs[m];
                     tmp[k] = a;
                 }
-                for (int k = 0; k < K; k++) { rhs[k] = tmp[k]; sol[k] += tmp[k]; }
+                LINCS_FOR(k) { rhs[k] = tmp[k]; sol[k] += tmp[k]; }
             }
-            for (int k = 0; k < K; k++) {
+            LINCS_FOR(k) {
                 const float l = S[k] * sol[k];
                 lamtot[k] += l;
                 const float3 da = (-ima[k] * l) * B[k], db = (imb[k] * l) * B[k];
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(128) void k_lincs(int ncomp, const int *__restrict_
         }
         if (VIRIAL) {
             const float s2 = inv_dt * inv_dt;
-            for (int k = 0; k < K; k++) {
+            LINCS_FOR(k) {
                 // force on atom a: -lam B / dt^2 ; r_ab = |r_old| B (old bond = constraint length)
                 const float g = -lamtot[k] * s2 * len[k];
                 v9[0] += B[k].x * B[k].x * g; v9[1] += B[k].x * B[k].y * g; v9[2] += B[k].x * B[k].z * g;
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(128) void k_lincs(int ncomp, const int *__restrict_
         __shared__ double red[16];
         for (int k = 0; k < 9; k++) {
             const double r = block_sum_d((double)v9[k], red);
-            if (threadIdx.x == 0) atomicAdd(&dw->vir[k], -0.5 * r);
+            if (threadIdx.x == 0) atomicAdd(&MDX_VIR(dw, k), -0.5 * r);
         }
     }
 }
@@ -214,32 +221,38 @@ __global__ __launch_bounds__(128) void k_lincs(int ncomp, const int *__restrict_
 __global__ __launch_bounds__(256) void k_ke(int n, const float4 *__restrict__ v, const int *__restrict__ tcgrp, int ntc,
                                             DevState *dw, int old_slot, int tensor)
 {
+    // grid-stride: a fixed, small number of workgroups keeps the count of contended double atomics low
     __shared__ double red[16];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    float ke = 0.0f; int g = 0;
-    float t6[6] = { 0, 0, 0, 0, 0, 0 };
-    if (i < n) {
+    double keg[MDX_MAX_TC];
+    double t6[6] = { 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+    for (int k = 0; k < MDX_MAX_TC; k++) keg[k] = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 vi = v[i];
         const float m = vi.w > 0.0f ? 1.0f / vi.w : 0.0f;
-        ke = 0.5f * m * (vi.x * vi.x + vi.y * vi.y + vi.z * vi.z);
-        g = tcgrp[i];
+        const float ke = 0.5f * m * (vi.x * vi.x + vi.y * vi.y + vi.z * vi.z);
+        const int g = tcgrp[i];
+#pragma unroll
+        for (int k = 0; k < MDX_MAX_TC; k++) keg[k] += (g == k) ? (double)ke : 0.0;
         if (tensor) {
-            t6[0] = 0.5f * m * vi.x * vi.x; t6[1] = 0.5f * m * vi.x * vi.y; t6[2] = 0.5f * m * vi.x * vi.z;
-            t6[3] = 0.5f * m * vi.y * vi.y; t6[4] = 0.5f * m * vi.y * vi.z; t6[5] = 0.5f * m * vi.z * vi.z;
+            t6[0] += 0.5f * m * vi.x * vi.x; t6[1] += 0.5f * m * vi.x * vi.y; t6[2] += 0.5f * m * vi.x * vi.z;
+            t6[3] += 0.5f * m * vi.y * vi.y; t6[4] += 0.5f * m * vi.y * vi.z; t6[5] += 0.5f * m * vi.z * vi.z;
         }
     }
     const int ng = ntc > 0 ? ntc : 1;
-    for (int k = 0; k < ng; k++) {
-        const double r = block_sum_d((g == k && i < n) ? (double)ke : 0.0, red);
+#pragma unroll
+    for (int k = 0; k < MDX_MAX_TC; k++) {
+        if (k >= ng) break;
+        const double r = block_sum_d(keg[k], red);
         if (threadIdx.x == 0 && r != 0.0) atomicAdd(old_slot ? &dw->ekinh_old[k] : &dw->ekinh[k], r);
     }
     if (tensor) {
         const int map[6][2] = { { 0, 0 }, { 1, 3 }, { 2, 6 }, { 4, 4 }, { 5, 7 }, { 8, 8 } };
         for (int k = 0; k < 6; k++) {
-            const double r = block_sum_d((double)t6[k], red);
+            const double r = block_sum_d(t6[k], red);
             if (threadIdx.x == 0) {
-                atomicAdd(&dw->ekin_tensor[map[k][0]], 0.5 * r);   // average of two half steps
-                if (map[k][1] != map[k][0]) atomicAdd(&dw->ekin_tensor[map[k][1]], 0.5 * r);
+                atomicAdd(&MDX_EKT(dw, map[k][0]), 0.5 * r);   // average of two half steps
+                if (map[k][1] != map[k][0]) atomicAdd(&MDX_EKT(dw, map[k][1]), 0.5 * r);
             }
         }
     }
@@ -274,6 +287,19 @@ __global__ void k_tcouple(DevState *dw, int ntc, const double *ref_t, const doub
 __global__ void k_finish_energy(DevState *dw, int ntc, double ndf_total, int dispcorr, double c6avg, int natoms,
                                 double rc, double q2sum, double beta, int have_pme)
 {
+    // fold the replicated accumulators (one quantity per thread), then thread 0 finishes
+    {
+        const int t = threadIdx.x;
+        if (t < MDX_E_N) { double a = 0.0; for (int r = 0; r < MDX_NREP; r++) a += dw->ener_rep[r][t]; dw->ener[t] += a; }
+        else if (t < MDX_E_N + 9) { const int k = t - MDX_E_N; double a = 0.0; for (int r = 0; r < MDX_NREP; r++) a += dw->vir_rep[r][k]; dw->vir[k] += a; }
+        else if (t < MDX_E_N + 18) { const int k = t - MDX_E_N - 9; double a = 0.0; for (int r = 0; r < MDX_NREP; r++) a += dw->ekt_rep[r][k]; dw->ekin_tensor[k] += a; }
+        else if (t < MDX_E_N + 20) {
+            const int k = t - MDX_E_N - 18; unsigned long long a = 0;
+            for (int r = 0; r < MDX_NREP; r++) a += dw->npairs_rep[r][k];
+            if (k == 0) dw->npairs_rc += a; else dw->npairs_lj += a;
+        }
+    }
+    __syncthreads();
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int ng = ntc > 0 ? ntc : 1;
     double ek = 0.0;
@@ -428,18 +454,21 @@ int mdx_launch_constrain(mdx_system *s, float inv_dt, bool virial, int lincs_ite
         if (virial) hipLaunchKernelGGL(k_settle<true>, dim3(nbw), dim3(256), 0, s->stream, s->nsettle, s->settle_idx, s->x, s->xp, s->v, s->settle_doh, s->settle_dhh, inv_dt, s->d);
         else hipLaunchKernelGGL(k_settle<false>, dim3(nbw), dim3(256), 0, s->stream, s->nsettle, s->settle_idx, s->x, s->xp, s->v, s->settle_doh, s->settle_dhh, inv_dt, s->d);
     }
-    if (s->ncomp > 0) {
-        const int nbc = (s->ncomp + 127) / 128;
-        if (virial) hipLaunchKernelGGL(k_lincs<true>, dim3(nbc), dim3(128), 0, s->stream, s->ncomp, s->comp_start, s->cons_ij, s->cons_len, s->x, s->xp, s->v, s->lincs_order, lincs_iter, inv_dt, s->d);
-        else hipLaunchKernelGGL(k_lincs<false>, dim3(nbc), dim3(128), 0, s->stream, s->ncomp, s->comp_start, s->cons_ij, s->cons_len, s->x, s->xp, s->v, s->lincs_order, lincs_iter, inv_dt, s->d);
+#define LAUNCH_LINCS(MAXK_, first, count)                                                                                  \
+    if ((count) > 0) {                                                                                                      \
+        const int nbc_ = ((count) + 127) / 128;                                                                             \
+        if (virial) hipLaunchKernelGGL((k_lincs<true, MAXK_>), dim3(nbc_), dim3(128), 0, s->stream, first, count, s->comp_start, s->cons_ij, s->cons_len, s->x, s->xp, s->v, s->lincs_order, lincs_iter, inv_dt, s->d); \
+        else hipLaunchKernelGGL((k_lincs<false, MAXK_>), dim3(nbc_), dim3(128), 0, s->stream, first, count, s->comp_start, s->cons_ij, s->cons_len, s->x, s->xp, s->v, s->lincs_order, lincs_iter, inv_dt, s->d); \
     }
+    LAUNCH_LINCS(4, 0, s->ncomp_small)
+    LAUNCH_LINCS(MDX_LINCS_MAXK, s->ncomp_small, s->ncomp - s->ncomp_small)
     MDX_CHECK(s, hipGetLastError());
     return MDX_OK;
 }
 
 int mdx_launch_ke(mdx_system *s, bool old_slot, bool tensor)
 {
-    const int nb = (s->n + 255) / 256;
+    const int nb = std::min((s->n + 255) / 256, 128);
     hipLaunchKernelGGL(k_ke, dim3(nb), dim3(256), 0, s->stream, s->n, s->v, s->tcgrp, s->ntc, s->d, old_slot ? 1 : 0, tensor ? 1 : 0);
     MDX_CHECK(s, hipGetLastError());
     return MDX_OK;
@@ -453,6 +482,11 @@ __global__ void k_clear(DevState *dw, int energies, int ekin_new, int ekin_old)
         if (t < MDX_E_N) dw->ener[t] = 0.0;
         if (t < 9) { dw->vir[t] = 0.0; dw->ekin_tensor[t] = 0.0; }
         if (t == 0) { dw->npairs_rc = 0; dw->npairs_lj = 0; }
+        if (t < MDX_NREP) {     // one replica row per thread
+            for (int k = 0; k < MDX_E_N; k++) dw->ener_rep[t][k] = 0.0;
+            for (int k = 0; k < 9; k++) { dw->vir_rep[t][k] = 0.0; dw->ekt_rep[t][k] = 0.0; }
+            dw->npairs_rep[t][0] = 0; dw->npairs_rep[t][1] = 0;
+        }
     }
     if (t < MDX_MAX_TC) {
         if (ekin_new) dw->ekinh[t] = 0.0;
