@@ -688,8 +688,10 @@ extern "C" int mdx_step(mdx_system *s, long long nsteps)
         // the leap-frog kernel leaves f cleared; only a force evaluation outside the step loop dirties it
         if (s->f_dirty) { MDX_CHECK(s, hipMemsetAsync(s->f, 0, sizeof(float) * 3 * s->n, s->stream)); s->f_dirty = false; }
         if (do_search) if ((rc = mdx_search(s))) return rc;
-        if ((rc = mdx_launch_prepare(s))) return rc;
+        // fork before the prepare kernel: the side streams read the state and the search arrays only, so
+        // prepare -> nonbonded run back to back on the main stream without an event between them
         if ((rc = mdx_fork(s))) return rc;
+        if ((rc = mdx_launch_prepare(s))) return rc;
         // the nonbonded kernel is the critical path: enqueue it first, the side streams fill in
         if ((rc = mdx_launch_nonbonded(s, need_vir, MDX_F_NONBONDED | (s->have_pme ? MDX_F_EXCL : 0)))) return rc;
         if ((rc = mdx_launch_pme(s, need_vir))) return rc;

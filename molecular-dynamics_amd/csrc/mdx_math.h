@@ -161,3 +161,11 @@ struct RngStream {
         return 2.0 * gamma(0.5 * n);
     }
 };
+
+// Lattice shift (multiples of the three box vectors) applied to an atom when it was wrapped into
+// the brick-shaped search cell, packed into one int (each component in -512..511).
+__device__ __forceinline__ int pack_shift(int a, int b, int c) { return (a + 512) | ((b + 512) << 10) | ((c + 512) << 20); }
+__device__ __forceinline__ void unpack_shift(int p, int &a, int &b, int &c)
+{
+    a = (p & 1023) - 512; b = ((p >> 10) & 1023) - 512; c = ((p >> 20) & 1023) - 512;
+}

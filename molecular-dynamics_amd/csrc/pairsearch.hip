@@ -15,11 +15,6 @@
 
 #define BIG_KEY 3.0e38f
 
-__device__ __forceinline__ int pack_shift(int a, int b, int c) { return (a + 512) | ((b + 512) << 10) | ((c + 512) << 20); }
-__device__ __forceinline__ void unpack_shift(int p, int &a, int &b, int &c)
-{
-    a = (p & 1023) - 512; b = ((p >> 10) & 1023) - 512; c = ((p >> 20) & 1023) - 512;
-}
 
 __global__ void k_bin(int n, const float4 *__restrict__ x, const DevState *__restrict__ d, int ncx, int ncy,
                       int *__restrict__ col_count, float4 *__restrict__ wrapped, int *__restrict__ atom_col,

@@ -51,7 +51,8 @@ __device__ __forceinline__ int pmod(int a, int K) { a %= K; return a < 0 ? a + K
 struct SpreadArgs {
     int ncx, ncy;
     const int *col_scstart;
-    const float4 *xq_s;
+    const float4 *x;             // state positions (original order)
+    const int *perm, *perm_src, *shift_s;   // sorted slot -> atom (-1 filler), source atom, packed lattice shift
     int K0, K1, K2;
     int T0, T1;          // LDS window per grid plane (x, y)
     int ppc;             // tile planes per workgroup
@@ -93,8 +94,18 @@ __global__ __launch_bounds__(256) void k_pme_spread_col(SpreadArgs A, const DevS
     __syncthreads();
     const int nwork = (a1 - a0) * 4;
     for (int w = threadIdx.x; w < nwork; w += blockDim.x) {
-        const float4 p = A.xq_s[a0 + (w >> 2)];
+        // position in the brick cell straight from the state: source atom of the sorted slot plus its
+        // stored lattice shift (what the prepare kernel writes for the nonbonded kernel; reading it
+        // here lets the PME stream start before that kernel has run)
+        const int gs = a0 + (w >> 2);
+        if (A.perm[gs] < 0) continue;                       // filler slot of a padded cluster
+        float4 p = A.x[A.perm_src[gs]];
         if (p.w == 0.0f) continue;
+        int sa, sb, sc;
+        unpack_shift(A.shift_s[gs], sa, sb, sc);
+        p.x += sa * bx.h[0] + sb * bx.h[3] + sc * bx.h[6];
+        p.y += sb * bx.h[4] + sc * bx.h[7];
+        p.z += sc * bx.h[8];
         float u[3];
         grid_coords(bx, p, A.K0, A.K1, A.K2, u);
         const int px = (int)floorf(u[0]), py = (int)floorf(u[1]), pz = (int)floorf(u[2]);
@@ -310,7 +321,7 @@ int mdx_launch_pme(mdx_system *s, bool energy)
         const double delta = 0.12;
         const double wx = bxd[0] / s->ncx + 2 * delta, wy = bxd[4] / s->ncy + 2 * delta, wz = 4.0 / (K2 * inv8) + 2 * delta;
         SpreadArgs A;
-        A.ncx = s->ncx; A.ncy = s->ncy; A.col_scstart = s->col_scstart; A.xq_s = s->xq_s; A.K0 = K0; A.K1 = K1; A.K2 = K2;
+        A.ncx = s->ncx; A.ncy = s->ncy; A.col_scstart = s->col_scstart; A.x = s->x; A.perm = s->perm; A.perm_src = s->perm_src; A.shift_s = s->shift_s; A.K0 = K0; A.K1 = K1; A.K2 = K2;
         A.T0 = std::min(K0, (int)ceil(K0 * (inv0 * wx + fabs(inv3) * wy + fabs(inv6) * wz)) + 5);
         A.T1 = std::min(K1, (int)ceil(K1 * (inv4 * wy + fabs(inv7) * wz)) + 5);
         const int planes = K2 + 8;
