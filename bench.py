@@ -187,6 +187,14 @@ def main():
         nb_avg_s = nb_ms / max(nb_launches, 1) * 1e-3
         achieved = flops / nb_avg_s / 1e12 if nb_avg_s > 0 else 0.0
         peak = 157.3
+        # HBM bytes per launch of the nonbonded kernel from the PMC passes kept under profiles/
+        # (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc runs; not collected live)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01", "nb_pmc_traffic.json")) as f:
+                traffic = float(json.load(f)["hbm_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "ns/day", "value": round(ns_day, 3), "unit": "ns/day", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 5), "higher_is_better": True,
@@ -206,7 +214,8 @@ def main():
             "pair_interactions_per_s": round(n_rc / nb_avg_s, 1) if nb_avg_s > 0 else None,
             "pair_interactions_per_s_end_to_end": round(n_rc * args.steps / elapsed_max * world, 1),
             "roofline": {"bound": "valu_f32", "kernel": "k_nonbonded", "achieved": round(achieved, 3), "peak": peak,
-                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (PMC, water box of the same size; profiles/r01/nb_pmc_traffic.json)",
                          "peak_unpacked": 78.6, "frac_unpacked": round(achieved / 78.6, 4),
                          "flops_per_launch": flops, "pairs_within_rc": n_rc, "pairs_with_lj": n_lj,
                          "avg_launch_ms": round(nb_avg_s * 1e3, 5), "launches": nb_launches,
