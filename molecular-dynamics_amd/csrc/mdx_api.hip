@@ -71,9 +71,9 @@ extern "C" mdx_system *mdx_create(int device, int natoms)
     const int n = natoms;
     s->ncol_cap = n / 128 + 256;
     s->npad = ((n + 63) / 64 + s->ncol_cap) * 64;
-    s->cj_cap = (n / 64 + 1) * 768 + 4096;
-    s->work_cap = s->cj_cap / 8 + 1024;
-    s->excl_cap = n + 1024;
+    s->cj_cap = (s->npad / 64) * MDX_CJ_PER_SC;
+    s->work_cap = (s->npad / 64) * MDX_WORK_PER_SC;
+    s->excl_cap = (s->npad / 64) * 4 * MDX_EXCL_PER_WAVE + 1;
     auto A = [&](auto **p, size_t c) { ok = ok && (dev_alloc(s, p, c) == MDX_OK); };
     A(&s->x, n); A(&s->xp, n); A(&s->v, n); A(&s->f, 3 * (size_t)n); A(&s->f_pme, 3 * (size_t)n); A(&s->lj, n); A(&s->molid, n); A(&s->tcgrp, n);
     A(&s->xq_s, s->npad); A(&s->lj_s, s->npad); A(&s->f_s, 3 * (size_t)s->npad); A(&s->perm, s->npad); A(&s->perm_src, s->npad);
@@ -81,7 +81,7 @@ extern "C" mdx_system *mdx_create(int device, int natoms)
     A(&s->bb_lo, s->npad / 8); A(&s->bb_hi, s->npad / 8); A(&s->sbb_lo, s->npad / 64); A(&s->sbb_hi, s->npad / 64);
     A(&s->col_count, s->ncol_cap + 1); A(&s->col_astart, s->ncol_cap + 1); A(&s->col_scstart, s->ncol_cap + 1); A(&s->col_atoms, n);
     A(&s->atom_col, n); A(&s->atom_slot, n); A(&s->wrapped, n);
-    A(&s->cj, s->cj_cap); A(&s->work, s->work_cap); A(&s->work_order, s->work_cap); A(&s->exclmask, (size_t)s->excl_cap * 64);
+    A(&s->cj, s->cj_cap); A(&s->work, s->work_cap); A(&s->work_order, s->work_cap); A(&s->sc_nwork, s->npad / 64); A(&s->exclmask, (size_t)s->excl_cap * 64);
     A(&s->shift_ijk, MDX_MAX_SHIFTS); A(&s->shiftvec, MDX_MAX_SHIFTS);
     A(&s->excl_start, n + 1); A(&s->excl_list, 1); A(&s->d_tc, 3 * MDX_MAX_TC);
     A(&s->d, 1);
@@ -113,7 +113,7 @@ extern "C" void mdx_destroy(mdx_system *s)
     mdx_frames_free(s);
     void *ptrs[] = { s->x, s->xp, s->v, s->f, s->f_pme, s->lj, s->molid, s->tcgrp, s->excl_start, s->excl_list, s->excl_pairs, s->xq_s, s->lj_s,
                      s->f_s, s->perm, s->perm_src, s->shift_s, s->molid_s, s->sorted_of, s->bb_lo, s->bb_hi, s->sbb_lo, s->sbb_hi,
-                     s->col_count, s->col_astart, s->col_scstart, s->col_atoms, s->atom_col, s->atom_slot, s->wrapped, s->cj, s->work, s->work_order,
+                     s->col_count, s->col_astart, s->col_scstart, s->col_atoms, s->atom_col, s->atom_slot, s->wrapped, s->cj, s->work, s->work_order, s->sc_nwork,
                      s->exclmask, s->shift_ijk, s->shiftvec, s->bond_ij, s->bond_p, s->angle_ijk, s->angle_p, s->dih_ijkl, s->dih_p,
                      s->pair_ij, s->pair_p, s->posres_idx, s->posres_ref, s->posres_k, s->settle_idx, s->cons_ij, s->cons_len,
                      s->comp_start, s->d_tc, s->pull_idx[0], s->pull_idx[1], s->d };
@@ -617,11 +617,7 @@ extern "C" int mdx_get_list_stats(mdx_system *s, long long *st)
     ARG_CHECK(s, st, "mdx_get_list_stats: null pointer");
     int rc = sync_and_check(s); if (rc) return rc;
     st[0] = s->h->nsc; st[1] = s->h->ncj; st[2] = s->h->nwork; st[3] = s->h->nexcl;
-    std::vector<NbEntry> e((size_t)std::max(0, std::min(s->h->ncj, s->cj_cap)));
-    if (!e.empty()) MDX_CHECK(s, hipMemcpy(e.data(), s->cj, sizeof(NbEntry) * e.size(), hipMemcpyDeviceToHost));
-    long long bits = 0;
-    for (const NbEntry &x : e) bits += __builtin_popcount(x.mask & 0xFFu);
-    st[4] = bits;
+    st[4] = (long long)s->h->ntiles;
     st[5] = (long long)s->h->npairs_rc; st[6] = (long long)s->h->npairs_lj; st[7] = 0;
     return MDX_OK;
 }

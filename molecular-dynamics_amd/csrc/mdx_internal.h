@@ -48,6 +48,7 @@ struct DevState {
     long long step;
     // pair counters of the last energy step: non-excluded pairs with r < rc, and those with LJ
     unsigned long long npairs_rc, npairs_lj;
+    unsigned long long ntiles;    // 8x8 tiles in the pair list (statistics)
     int work_head[8];             // per-queue dequeue counters of the nonbonded kernel (cleared every step)
     // Replicated accumulators of the energy steps: thousands of workgroups adding doubles to one
     // address serialise in L2, so each adds to replica (block index mod MDX_NREP) and
@@ -65,6 +66,11 @@ __device__ __forceinline__ int mdx_rep() { return (int)((blockIdx.x + 5u * block
 #define MDX_EKT(dw, k) ((dw)->ekt_rep[mdx_rep()][k])
 #endif
 
+// The pair list has a fixed region per i-super-cluster (and, for exclusion masks, per wave of the
+// list builder), so building it needs no global counters.
+#define MDX_CJ_PER_SC 1024
+#define MDX_WORK_PER_SC 64
+#define MDX_EXCL_PER_WAVE 48
 struct NbEntry { int cj; unsigned int mask; };        // mask: bits 0-7 i-cluster mask, bits 8.. exclusion slot
 struct NbWork { int sci; int shift; int cj_start; int cj_end; };
 
@@ -118,6 +124,7 @@ struct mdx_system {
     NbEntry *cj = nullptr; int cj_cap = 0;
     NbWork *work = nullptr; int work_cap = 0;
     int *work_order = nullptr;    // unit indices by descending tile count
+    int *sc_nwork = nullptr;      // work units in use per i-super-cluster
     unsigned char *exclmask = nullptr; int excl_cap = 0;
     int nshift = 0, central_shift = 0;
     int3 *shift_ijk = nullptr;    // device

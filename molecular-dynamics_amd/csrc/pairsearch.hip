@@ -70,7 +70,7 @@ __global__ void k_colscan(int ncol, const int *__restrict__ col_count, int *__re
         int ra = 0, rs = 0;
         for (int k = 0; k < (int)blockDim.x; k++) { int ta = sa[k], ts = ss[k]; sa[k] = ra; ss[k] = rs; ra += ta; rs += ts; }
         col_astart[ncol] = ra; col_scstart[ncol] = rs;
-        d->nsc = rs; d->ncj = 0; d->nwork = 0; d->nexcl = 1;
+        d->nsc = rs; d->ncj = 0; d->nwork = 0; d->nexcl = 1; d->ntiles = 0;
         if (rs > nsc_cap) d->overflow |= 16;
     }
     __syncthreads();
@@ -221,9 +221,10 @@ struct ListArgs {
     const float4 *shiftvec;
     int nshift, central;
     const int *excl_start, *excl_list;
-    NbEntry *cj; int cj_cap;
-    NbWork *work; int work_cap;
-    unsigned char *exclmask; int excl_cap;
+    NbEntry *cj;                 // MDX_CJ_PER_SC entries per i-super-cluster
+    NbWork *work;                // MDX_WORK_PER_SC units per i-super-cluster
+    int *sc_nwork;               // units in use per i-super-cluster
+    unsigned char *exclmask;     // 64-byte masks, MDX_EXCL_PER_WAVE slots per (super-cluster, wave)
     float rlist;
 };
 
@@ -238,7 +239,8 @@ __global__ __launch_bounds__(256) void k_build_list(ListArgs A)
     __shared__ int mol_sh[64];
     __shared__ int orig_sh[64];
     __shared__ NbEntry ebuf[EBUF];
-    __shared__ int s_nent, s_start, s_w0;
+    __shared__ int s_nent, s_start, s_w0, s_tiles;     // entries of the current shift; entries, units, tiles so far
+    int wslots = 0;                                     // exclusion-mask slots used by this wave (wave-uniform)
     __shared__ float4 xj_sh[4][64];      // per wave: the 64 atoms of the candidate j-super-cluster
     __shared__ int molj_sh[4][64];
     __shared__ int origj_sh[4][64];
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256) void k_build_list(ListArgs A)
         mol_sh[lane] = A.molid_s[sci * 64 + lane];
         orig_sh[lane] = A.perm[sci * 64 + lane];
     }
-    if (threadIdx.x == 0) s_nent = 0;
+    if (threadIdx.x == 0) { s_nent = 0; s_start = 0; s_w0 = 0; s_tiles = 0; }
     const float4 slo4 = A.sbb_lo[sci], shi4 = A.sbb_hi[sci];
     const int ti = lane & 7, tj = lane >> 3;
     const float4 ilo4 = A.bb_lo[sci * 8 + ti], ihi4 = A.bb_hi[sci * 8 + ti];
@@ -327,10 +329,12 @@ __global__ __launch_bounds__(256) void k_build_list(ListArgs A)
                             const bool need = __any((exb & newim) != newim);
                             int slot = 0;
                             if (need) {
-                                if (lane == 0) slot = atomicAdd(&A.d->nexcl, 1);
-                                slot = __shfl(slot, 0, 64);
-                                if (slot < A.excl_cap) A.exclmask[(size_t)slot * 64 + lane] = (unsigned char)exb;
-                                else { slot = 0; if (lane == 0) atomicOr(&A.d->overflow, 4); }
+                                // mask slots come from a region owned by this wave: no returning atomic
+                                if (wslots < MDX_EXCL_PER_WAVE) {
+                                    slot = 1 + (sci * 4 + wv) * MDX_EXCL_PER_WAVE + wslots;
+                                    wslots++;
+                                    A.exclmask[(size_t)slot * 64 + lane] = (unsigned char)exb;
+                                } else if (lane == 0) atomicOr(&A.d->overflow, 4);
                             }
                             if (lane == 0) {
                                 const int idx = atomicAdd(&s_nent, 1);
@@ -345,10 +349,9 @@ __global__ __launch_bounds__(256) void k_build_list(ListArgs A)
         const int nent = min(s_nent, EBUF);
         if (nent) {
             const int nw = (nent + MDX_NB_CHUNK - 1) / MDX_NB_CHUNK;
-            if (threadIdx.x == 0) { s_start = atomicAdd(&A.d->ncj, nent); s_w0 = atomicAdd(&A.d->nwork, nw); }
-            __syncthreads();
-            const int start = s_start, w0 = s_w0;
-            if (start + nent <= A.cj_cap && w0 + nw <= A.work_cap) {
+            // entries and work units go to regions owned by this super-cluster: no global counters
+            const int start = sci * MDX_CJ_PER_SC + s_start, w0 = sci * MDX_WORK_PER_SC + s_w0;
+            if (s_start + nent <= MDX_CJ_PER_SC && s_w0 + nw <= MDX_WORK_PER_SC) {
                 for (int k = threadIdx.x; k < nent; k += 256) A.cj[start + k] = ebuf[k];
                 for (int k = threadIdx.x; k < nw; k += 256) {
                     NbWork w; w.sci = sci; w.cj_start = start + k * MDX_NB_CHUNK;
@@ -358,36 +361,51 @@ __global__ __launch_bounds__(256) void k_build_list(ListArgs A)
                     for (int q = k * MDX_NB_CHUNK; q < min(nent, (k + 1) * MDX_NB_CHUNK); q++) cost += __popc(ebuf[q].mask & 0xFFu);
                     w.shift = s | (cost << 8);
                     A.work[w0 + k] = w;
+                    atomicAdd(&s_tiles, cost);
                 }
-            } else if (threadIdx.x == 0) atomicOr(&A.d->overflow, (start + nent > A.cj_cap) ? 1 : 2);
+            } else if (threadIdx.x == 0) atomicOr(&A.d->overflow, (s_start + nent > MDX_CJ_PER_SC) ? 1 : 2);
             __syncthreads();
-            if (threadIdx.x == 0) s_nent = 0;
+            if (threadIdx.x == 0) {
+                s_start += nent; s_w0 += nw; s_nent = 0;
+            }
         }
         __syncthreads();
     }
+    if (threadIdx.x == 0) {
+        A.sc_nwork[sci] = min(s_w0, MDX_WORK_PER_SC);
+        atomicAdd(&A.d->ncj, min(s_start, MDX_CJ_PER_SC));       // statistics only (no value returned)
+        atomicAdd(&A.d->ntiles, (unsigned long long)s_tiles);
+    }
+    if (lane == 0 && wslots) atomicAdd(&A.d->nexcl, wslots);
 }
 
 // Order the work units by descending tile count (counting sort on the cost stored next to the
 // shift index). The nonbonded kernel hands unit k, k+W, k+2W, ... to wave k, so every wave gets
 // one unit of each cost tier and the waves finish together.
-__global__ void k_sort_work(const DevState *__restrict__ d, const NbWork *__restrict__ work, int *__restrict__ order, int cap)
+// The unit array is sparse (a fixed region per i-super-cluster, sc_nwork[] of it in use): the sort
+// visits every region, orders the units in use and stores their count.
+__global__ void k_sort_work(DevState *__restrict__ d, const NbWork *__restrict__ work, const int *__restrict__ sc_nwork,
+                            int *__restrict__ order)
 {
     __shared__ int hist[257];
     __shared__ int first[257];
-    const int n = min(d->nwork, cap);
+    const int n = d->nsc * MDX_WORK_PER_SC;
     for (int c = threadIdx.x; c < 257; c += blockDim.x) hist[c] = 0;
     __syncthreads();
-    for (int k = threadIdx.x; k < n; k += blockDim.x) atomicAdd(&hist[min(256, work[k].shift >> 8)], 1);
+    for (int k = threadIdx.x; k < n; k += blockDim.x)
+        if ((k % MDX_WORK_PER_SC) < sc_nwork[k / MDX_WORK_PER_SC]) atomicAdd(&hist[min(256, work[k].shift >> 8)], 1);
     __syncthreads();
     if (threadIdx.x == 0) {
         int run = 0;
         for (int c = 256; c >= 0; c--) { first[c] = run; run += hist[c]; }
+        d->nwork = run;
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < n; k += blockDim.x) {
-        const int pos = atomicAdd(&first[min(256, work[k].shift >> 8)], 1);
-        order[pos] = k;
-    }
+    for (int k = threadIdx.x; k < n; k += blockDim.x)
+        if ((k % MDX_WORK_PER_SC) < sc_nwork[k / MDX_WORK_PER_SC]) {
+            const int pos = atomicAdd(&first[min(256, work[k].shift >> 8)], 1);
+            order[pos] = k;
+        }
 }
 
 // Per step: refresh the sorted coordinates from the state and clear the sorted force buffer.
@@ -491,11 +509,11 @@ int mdx_search(mdx_system *s)
     A.dro = s->d; A.d = s->d; A.ncx = ncx; A.ncy = ncy; A.col_scstart = s->col_scstart; A.xq_s = s->xq_s; A.perm = s->perm;
     A.molid_s = s->molid_s; A.bb_lo = s->bb_lo; A.bb_hi = s->bb_hi; A.sbb_lo = s->sbb_lo; A.sbb_hi = s->sbb_hi;
     A.shiftvec = s->shiftvec; A.nshift = s->nshift; A.central = s->central_shift; A.excl_start = s->excl_start;
-    A.excl_list = s->excl_list; A.cj = s->cj; A.cj_cap = s->cj_cap; A.work = s->work; A.work_cap = s->work_cap;
-    A.exclmask = s->exclmask; A.excl_cap = s->excl_cap; A.rlist = s->rlist;
+    A.excl_list = s->excl_list; A.cj = s->cj; A.work = s->work; A.sc_nwork = s->sc_nwork;
+    A.exclmask = s->exclmask; A.rlist = s->rlist;
     const int nblk = s->npad / 64;
     hipLaunchKernelGGL(k_build_list, dim3(nblk), dim3(256), 0, s->stream, A);
-    hipLaunchKernelGGL(k_sort_work, dim3(1), dim3(1024), 0, s->stream, s->d, s->work, s->work_order, s->work_cap);
+    hipLaunchKernelGGL(k_sort_work, dim3(1), dim3(1024), 0, s->stream, s->d, s->work, s->sc_nwork, s->work_order);
     MDX_CHECK(s, hipGetLastError());
     s->steps_since_search = 0;
     return MDX_OK;
