@@ -229,6 +229,7 @@ struct ListArgs {
 };
 
 #define EBUF 1024
+#define EXCL_SH 32         // exclusions per i-atom held in LDS (longer lists are read from global memory)
 
 // One workgroup (4 waves) per i-super-cluster: the waves share the i-atoms in LDS, take the
 // candidate j-super-clusters round-robin and append entries to one LDS buffer, which is flushed
@@ -239,6 +240,8 @@ __global__ __launch_bounds__(256) void k_build_list(ListArgs A)
     __shared__ int mol_sh[64];
     __shared__ int orig_sh[64];
     __shared__ NbEntry ebuf[EBUF];
+    __shared__ int excl_sh[EXCL_SH * 64];              // [entry][i-atom]: excluded partners (original indices)
+    __shared__ int excl_n[64], excl_lo[64], excl_hi[64];
     __shared__ int s_nent, s_start, s_w0, s_tiles;     // entries of the current shift; entries, units, tiles so far
     int wslots = 0;                                     // exclusion-mask slots used by this wave (wave-uniform)
     __shared__ float4 xj_sh[4][64];      // per wave: the 64 atoms of the candidate j-super-cluster
@@ -257,6 +260,20 @@ __global__ __launch_bounds__(256) void k_build_list(ListArgs A)
         orig_sh[lane] = A.perm[sci * 64 + lane];
     }
     if (threadIdx.x == 0) { s_nent = 0; s_start = 0; s_w0 = 0; s_tiles = 0; }
+    {
+        // exclusion lists of the 64 i-atoms, staged once: the per-pair test below then reads LDS only
+        const int a = lane, oi = A.perm[sci * 64 + a];
+        const int e0 = oi >= 0 ? A.excl_start[oi] : 0, e1 = oi >= 0 ? A.excl_start[oi + 1] : 0;
+        int lo = 0x7fffffff, hi = -1;
+        for (int k = e0 + wv; k < e1; k += 4) {
+            const int j = A.excl_list[k];
+            lo = min(lo, j); hi = max(hi, j);
+            if (k - e0 < EXCL_SH) excl_sh[(k - e0) * 64 + a] = j;
+        }
+        if (wv == 0) { excl_n[a] = e1 - e0; excl_lo[a] = 0x7fffffff; excl_hi[a] = -1; }
+        __syncthreads();
+        if (hi >= 0) { atomicMin(&excl_lo[a], lo); atomicMax(&excl_hi[a], hi); }
+    }
     const float4 slo4 = A.sbb_lo[sci], shi4 = A.sbb_hi[sci];
     const int ti = lane & 7, tj = lane >> 3;
     const float4 ilo4 = A.bb_lo[sci * 8 + ti], ihi4 = A.bb_hi[sci * 8 + ti];
@@ -316,11 +333,16 @@ __global__ __launch_bounds__(256) void k_build_list(ListArgs A)
                                 // bit cleared = topologically excluded pair (the nonbonded kernel gives those the
                                 // Ewald correction and itself skips the lower half of a cluster's tile with itself)
                                 bool ex = false;
-                                if (molj >= 0 && mol_sh[ci * 8 + ti] == molj && !(central && cjg == sci * 8 + ci && tj == ti)) {
-                                    const int oi = orig_sh[ci * 8 + ti];
-                                    const int e0 = A.excl_start[oi], e1 = A.excl_start[oi + 1];
-                                    for (int k = e0; k < e1; k++)
-                                        if (A.excl_list[k] == origj) { ex = true; break; }
+                                const int ia = ci * 8 + ti;
+                                if (molj >= 0 && mol_sh[ia] == molj && origj >= excl_lo[ia] && origj <= excl_hi[ia] &&
+                                    !(central && cjg == sci * 8 + ci && tj == ti)) {
+                                    const int ne = excl_n[ia];
+                                    if (ne <= EXCL_SH) {
+                                        for (int k = 0; k < ne; k++) ex = ex || (excl_sh[k * 64 + ia] == origj);
+                                    } else {
+                                        const int e0 = A.excl_start[orig_sh[ia]];
+                                        for (int k = 0; k < ne; k++) ex = ex || (A.excl_list[e0 + k] == origj);
+                                    }
                                 }
                                 if (ex) exb &= ~(1u << ci);
                                 if (__any(in)) newim |= (1u << ci);
