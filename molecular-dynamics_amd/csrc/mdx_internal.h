@@ -49,6 +49,8 @@ struct DevState {
     // pair counters of the last energy step: non-excluded pairs with r < rc, and those with LJ
     unsigned long long npairs_rc, npairs_lj;
     unsigned long long ntiles;    // 8x8 tiles in the pair list (statistics)
+    int cost_hist[258];           // work units per tile count (last bin: 256 and more), filled by the list builder
+    int cost_cursor[258];         // positions handed out per tile count by the sort of the units
     int work_head[8];             // per-queue dequeue counters of the nonbonded kernel (cleared every step)
     // Replicated accumulators of the energy steps: thousands of workgroups adding doubles to one
     // address serialise in L2, so each adds to replica (block index mod MDX_NREP) and
@@ -183,6 +185,7 @@ struct mdx_system {
     // energy history ring (pinned)
     double *ener_log = nullptr; int ener_log_cap = 0; long long ener_log_count = 0;
     // timing of the dominant kernel (HIP events on this stream)
+    unsigned nb_launch_seq = 0;
     bool time_nb = false; std::vector<hipEvent_t> ev_pool; std::vector<std::pair<int, int>> ev_nb;
     double nb_ms_total = 0; long long nb_launches = 0;
     void *frame_ring = nullptr;   // pinned trajectory-frame slots (runctl.hip)

@@ -73,6 +73,7 @@ __global__ void k_colscan(int ncol, const int *__restrict__ col_count, int *__re
         d->nsc = rs; d->ncj = 0; d->nwork = 0; d->nexcl = 1; d->ntiles = 0;
         if (rs > nsc_cap) d->overflow |= 16;
     }
+    if (t < 257) { d->cost_hist[t] = 0; d->cost_cursor[t] = 0; }
     __syncthreads();
     a = sa[t]; s = ss[t];
     for (int c = b; c < e; c++) {
@@ -117,7 +118,7 @@ __device__ void bitonic_blocks(float *k, float *c1, float *c2, int *id, int P, i
     }
 }
 
-__global__ __launch_bounds__(256) void k_sortcol(const int *__restrict__ col_count, const int *__restrict__ col_astart,
+__global__ __launch_bounds__(1024) void k_sortcol(const int *__restrict__ col_count, const int *__restrict__ col_astart,
                                                  const int *__restrict__ col_scstart, const int *__restrict__ col_atoms,
                                                  const float4 *__restrict__ wrapped, const float4 *__restrict__ x,
                                                  const float2 *__restrict__ lj, const int *__restrict__ molid,
@@ -226,62 +227,86 @@ struct ListArgs {
     int *sc_nwork;               // units in use per i-super-cluster
     unsigned char *exclmask;     // 64-byte masks, MDX_EXCL_PER_WAVE slots per (super-cluster, wave)
     float rlist;
+    int dbg;                     // diagnostic ablation bits (timing experiments only)
 };
 
-#define EBUF 1024
-#define EXCL_SH 32         // exclusions per i-atom held in LDS (longer lists are read from global memory)
+#define EBUF 768          // entries of one (super-cluster, shift) buffered in LDS
 
 // One workgroup (4 waves) per i-super-cluster: the waves share the i-atoms in LDS, take the
 // candidate j-super-clusters round-robin and append entries to one LDS buffer, which is flushed
 // once per lattice shift so the entries of a (super-cluster, shift) stay contiguous.
-__global__ __launch_bounds__(256) void k_build_list(ListArgs A)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_build_list(ListArgs A)
 {
     __shared__ float4 xi_sh[64];
-    __shared__ int mol_sh[64];
     __shared__ int orig_sh[64];
     __shared__ NbEntry ebuf[EBUF];
-    __shared__ int excl_sh[EXCL_SH * 64];              // [entry][i-atom]: excluded partners (original indices)
     __shared__ int excl_n[64], excl_lo[64], excl_hi[64];
+    __shared__ unsigned excl_bits[128];                // per i-atom: 64-bit membership mask relative to excl_lo
+    __shared__ unsigned excl_bloom[256];               // bit (j mod 8192) set for every partner j in those lists
     __shared__ int s_nent, s_start, s_w0, s_tiles;     // entries of the current shift; entries, units, tiles so far
     int wslots = 0;                                     // exclusion-mask slots used by this wave (wave-uniform)
     __shared__ float4 xj_sh[4][64];      // per wave: the 64 atoms of the candidate j-super-cluster
-    __shared__ int molj_sh[4][64];
     __shared__ int origj_sh[4][64];
+    __shared__ __align__(8) unsigned char ext_sh[4][64];   // per wave: exclusion bytes being transposed
+    __shared__ int row_first[4][64], row_scb[4][64], row_total[4];   // per wave: flat candidate space of the grid rows
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int sci = blockIdx.x;
     const int nsc = A.dro->nsc;
     if (sci >= nsc) return;                     // uniform for the whole workgroup
     const float rl2 = A.rlist * A.rlist;
+    const float rbb = fmaxf(0.0f, A.rlist - 0.3f), rbb2 = rbb * rbb;
     const float *h = A.dro->box.h;
     const float wx = h[0] / A.ncx, wy = h[4] / A.ncy, cz = h[8];
     if (threadIdx.x < 64) {
         xi_sh[lane] = A.xq_s[sci * 64 + lane];
-        mol_sh[lane] = A.molid_s[sci * 64 + lane];
         orig_sh[lane] = A.perm[sci * 64 + lane];
     }
     if (threadIdx.x == 0) { s_nent = 0; s_start = 0; s_w0 = 0; s_tiles = 0; }
     {
-        // exclusion lists of the 64 i-atoms, staged once: the per-pair test below then reads LDS only
+        // exclusion lists of the 64 i-atoms, condensed once into LDS: index range, membership bit mask over
+        // that range and a filter over all partners; the per-pair test below then reads registers and LDS only
         const int a = lane, oi = A.perm[sci * 64 + a];
         const int e0 = oi >= 0 ? A.excl_start[oi] : 0, e1 = oi >= 0 ? A.excl_start[oi + 1] : 0;
+        excl_bloom[threadIdx.x] = 0u;
+        if (threadIdx.x < 128) excl_bits[threadIdx.x] = 0u;
+        if (wv == 0) { excl_n[a] = e1 - e0; excl_lo[a] = 0x7fffffff; excl_hi[a] = -1; }
+        __syncthreads();
         int lo = 0x7fffffff, hi = -1;
         for (int k = e0 + wv; k < e1; k += 4) {
             const int j = A.excl_list[k];
             lo = min(lo, j); hi = max(hi, j);
-            if (k - e0 < EXCL_SH) excl_sh[(k - e0) * 64 + a] = j;
+            atomicOr(&excl_bloom[(j >> 5) & 255], 1u << (j & 31));
         }
-        if (wv == 0) { excl_n[a] = e1 - e0; excl_lo[a] = 0x7fffffff; excl_hi[a] = -1; }
-        __syncthreads();
         if (hi >= 0) { atomicMin(&excl_lo[a], lo); atomicMax(&excl_hi[a], hi); }
+        __syncthreads();
+        // lists spanning fewer than 64 indices (all but exotic topologies) become a bit mask over [lo, lo + 63]
+        const int flo = excl_lo[a];
+        if (excl_hi[a] - flo < 64)
+            for (int k = e0 + wv; k < e1; k += 4) {
+                const int m = A.excl_list[k] - flo;
+                atomicOr(&excl_bits[a * 2 + (m >> 5)], 1u << (m & 31));
+            }
     }
     const float4 slo4 = A.sbb_lo[sci], shi4 = A.sbb_hi[sci];
     const int ti = lane & 7, tj = lane >> 3;
     const float4 ilo4 = A.bb_lo[sci * 8 + ti], ihi4 = A.bb_hi[sci * 8 + ti];
     __syncthreads();
+    float xi_r[8][3];
+    // i-atom `lane` of the super-cluster: range, span and membership bits of its exclusion list
+    // (an atom without exclusions has a range no index falls in)
+    const int my_elo = excl_lo[lane];
+    const unsigned my_espan = (unsigned)(excl_hi[lane] - my_elo);
+    const unsigned my_eb0 = excl_bits[lane * 2], my_eb1 = excl_bits[lane * 2 + 1];
+#pragma unroll
+    for (int ci = 0; ci < 8; ci++) {
+        const float4 xi = xi_sh[ci * 8 + ti];
+        xi_r[ci][0] = xi.x; xi_r[ci][1] = xi.y; xi_r[ci][2] = xi.z;
+    }
 
     for (int s = 0; s < A.nshift; s++) {
         const float4 S = A.shiftvec[s];
         const bool central = (s == A.central);
+        if ((A.dbg & 2048) && !central) continue;
         const float3 slo = make_float3(slo4.x - S.x, slo4.y - S.y, slo4.z - S.z);
         const float3 shi = make_float3(shi4.x - S.x, shi4.y - S.y, shi4.z - S.z);
         if (shi.z + A.rlist < 0.0f || slo.z - A.rlist > cz) continue;
@@ -290,62 +315,109 @@ __global__ __launch_bounds__(256) void k_build_list(ListArgs A)
         if (cx0 > cx1 || cy0 > cy1) continue;
         const float3 ilo = make_float3(ilo4.x - S.x, ilo4.y - S.y, ilo4.z - S.z);
         const float3 ihi = make_float3(ihi4.x - S.x, ihi4.y - S.y, ihi4.z - S.z);
-        int cand = 0;
-        for (int cy = cy0; cy <= cy1; cy++)
-            for (int cx = cx0; cx <= cx1; cx++) {
-                const int col = cy * A.ncx + cx;
-                const int scb = A.col_scstart[col], sce = A.col_scstart[col + 1];
-                for (int base = scb; base < sce; base += 64) {
-                    const int scj_l = base + lane;
-                    bool ok = scj_l < sce;
+        // Candidate j-super-clusters. Columns are numbered x-fastest and a column's super-clusters are
+        // contiguous, so the window [cx0,cx1] of one grid row is one contiguous index range: lanes fetch
+        // the row ranges, a wave scan turns them into one flat candidate space, and the four waves
+        // take its elements round-robin, 64 at a time (one global round trip per 256 candidates).
+        const int nyw = cy1 - cy0 + 1;
+        for (int r0 = 0; r0 < nyw; r0 += 64) {
+            {
+                const int r = r0 + lane;
+                const bool lv = r < nyw;
+                const int rowc = (cy0 + r) * A.ncx;
+                const int rb = lv ? A.col_scstart[rowc + cx0] : 0, re = lv ? A.col_scstart[rowc + cx1 + 1] : 0;
+                int incl = re - rb;
+                for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+                __builtin_amdgcn_wave_barrier();
+                row_first[wv][lane] = lv ? incl - (re - rb) : 0x7fffffff;
+                row_scb[wv][lane] = rb;
+                row_total[wv] = __shfl(incl, 63, 64);
+                __builtin_amdgcn_wave_barrier();
+            }
+            const int T = row_total[wv];
+            for (int it = 0; it * 256 < T; it++) {
+                    const int fl = (it * 64 + lane) * 4 + wv;
+                    bool ok = fl < T;
+                    int l = 0;
+                    for (int step = 32; step; step >>= 1) if (row_first[wv][l + step] <= fl) l += step;
+                    const int scj_l = row_scb[wv][l] + (fl - row_first[wv][l]);
                     if (central) ok = ok && (scj_l >= sci);
                     if (ok) ok = bb_dist2(slo, shi, A.sbb_lo[scj_l], A.sbb_hi[scj_l]) < rl2;
                     unsigned long long m = __ballot(ok);
+                    if (A.dbg & 4096) m = 0;
                     while (m) {
                         const int b = __ffsll((long long)m) - 1;
                         m &= m - 1;
-                        if (((cand++) & 3) != wv) continue;      // this candidate belongs to another wave
-                        const int scj = base + b;
-                        // cluster level: lane = (i-cluster ti, j-cluster tj)
-                        bool okc = bb_dist2(ilo, ihi, A.bb_lo[scj * 8 + tj], A.bb_hi[scj * 8 + tj]) < rl2;
+                        const int scj = __builtin_amdgcn_readlane(scj_l, b);
+                        // cluster level: lane = (i-cluster ti, j-cluster tj); the atoms of the j-super-cluster
+                        // are fetched in the same round trip as its cluster boxes
+                        const float4 jlo = A.bb_lo[scj * 8 + tj], jhi = A.bb_hi[scj * 8 + tj];
+                        const float4 xjv = A.xq_s[scj * 64 + lane];
+                        const int ojv = A.perm[scj * 64 + lane];
+                        const float bd2 = bb_dist2(ilo, ihi, jlo, jhi);
+                        bool okc = bd2 < rl2;
                         if (central && scj == sci) okc = okc && (tj >= ti);
                         const unsigned long long cm = __ballot(okc);
-                        if (!cm) continue;
-                        // one coalesced fetch of the whole j-super-cluster instead of 8 dependent ones
-                        xj_sh[wv][lane] = A.xq_s[scj * 64 + lane];
-                        molj_sh[wv][lane] = A.molid_s[scj * 64 + lane];
-                        origj_sh[wv][lane] = A.perm[scj * 64 + lane];
+                        // boxes this close hold a pair within rlist almost surely: listed without the atom test
+                        // (a tile listed in vain costs the nonbonded kernel one skipped tile, never correctness)
+                        const unsigned long long cs = __ballot(okc && bd2 < rbb2) & ((A.dbg & 8192) ? 0ull : ~0ull);
+                        if (!cm || (A.dbg & 1024)) continue;
+                        // j-atoms whose index has its bit in the filter over all exclusion partners of the i-atoms
+                        const unsigned long long bh = (A.dbg & 16384) ? 0ull :
+                            __ballot(ojv >= 0 && ((excl_bloom[(ojv >> 5) & 255] >> (ojv & 31)) & 1u));
+                        xj_sh[wv][lane] = xjv;
+                        origj_sh[wv][lane] = ojv;
                         __builtin_amdgcn_wave_barrier();
                         for (int cjl = 0; cjl < 8; cjl++) {
                             const unsigned im = (unsigned)((cm >> (8 * cjl)) & 0xFFull);
                             if (!im) continue;
                             const int cjg = scj * 8 + cjl;
-                            // atom level: lane = (i-atom ti, j-atom tj)
+                            // atom level: lane = (i-atom ti, j-atom tj); the lane's eight i-atoms are in registers
                             const float4 xj = xj_sh[wv][cjl * 8 + tj];
-                            const int molj = molj_sh[wv][cjl * 8 + tj];
                             const int origj = origj_sh[wv][cjl * 8 + tj];
-                            unsigned newim = 0, exb = 0xFF;
-                            for (int ci = 0; ci < 8; ci++) {
-                                if (!(im & (1u << ci))) continue;
-                                const float4 xi = xi_sh[ci * 8 + ti];
-                                const float dx = xi.x - S.x - xj.x, dy = xi.y - S.y - xj.y, dz = xi.z - S.z - xj.z;
-                                const bool in = (dx * dx + dy * dy + dz * dz) < rl2;
-                                // bit cleared = topologically excluded pair (the nonbonded kernel gives those the
-                                // Ewald correction and itself skips the lower half of a cluster's tile with itself)
-                                bool ex = false;
-                                const int ia = ci * 8 + ti;
-                                if (molj >= 0 && mol_sh[ia] == molj && origj >= excl_lo[ia] && origj <= excl_hi[ia] &&
-                                    !(central && cjg == sci * 8 + ci && tj == ti)) {
-                                    const int ne = excl_n[ia];
-                                    if (ne <= EXCL_SH) {
-                                        for (int k = 0; k < ne; k++) ex = ex || (excl_sh[k * 64 + ia] == origj);
-                                    } else {
-                                        const int e0 = A.excl_start[orig_sh[ia]];
-                                        for (int k = 0; k < ne; k++) ex = ex || (A.excl_list[e0 + k] == origj);
-                                    }
+                            const float xjs = xj.x + S.x, yjs = xj.y + S.y, zjs = xj.z + S.z;
+                            const unsigned sure = (unsigned)((cs >> (8 * cjl)) & 0xFFull);
+                            unsigned newim = sure, exb = 0xFF;
+                            const unsigned test = im & ~sure;
+                            if (A.dbg & 512) newim = im;
+                            else if (test) {
+#pragma unroll
+                                for (int ci = 0; ci < 8; ci++) {
+                                    if (!(test & (1u << ci))) continue;       // wave-uniform
+                                    const float dx = xi_r[ci][0] - xjs, dy = xi_r[ci][1] - yjs, dz = xi_r[ci][2] - zjs;
+                                    if (__any((dx * dx + dy * dy + dz * dz) < rl2)) newim |= (1u << ci);
                                 }
-                                if (ex) exb &= ~(1u << ci);
-                                if (__any(in)) newim |= (1u << ci);
+                            }
+                            // bit cleared in exb = topologically excluded pair (the nonbonded kernel gives those the
+                            // Ewald correction and itself skips the lower half of a cluster's tile with itself).
+                            // Looked up only when the filter has the bit of one of the cluster's j-atoms. For the lookup lane a is i-atom a against the eight j-atoms (registers
+                            // only); the resulting bytes are transposed through LDS into the (ti, tj) lane layout.
+                            if (newim && ((bh >> (8 * cjl)) & 0xFFull)) {
+                                unsigned exj = 0;
+#pragma unroll
+                                for (int k = 0; k < 8; k++) {
+                                    const int oj = origj_sh[wv][cjl * 8 + k];
+                                    const unsigned dlt = (unsigned)(oj - my_elo);
+                                    bool ex = dlt <= my_espan && ((((dlt & 32u) ? my_eb1 : my_eb0) >> (dlt & 31u)) & 1u);
+                                    if (my_espan >= 64u && my_espan < 0x80000000u && dlt <= my_espan) {
+                                        const int e0 = A.excl_start[orig_sh[lane]], ne = excl_n[lane];
+                                        for (int q = 0; q < ne; q++) ex = ex || (A.excl_list[e0 + q] == oj);
+                                    }
+                                    if (ex && !(central && sci * 64 + lane == cjg * 8 + k)) exj |= 1u << k;
+                                }
+                                if (__any(exj != 0u)) {
+                                    ext_sh[wv][ti * 8 + tj] = (unsigned char)exj;       // lane = i-atom tj * 8 + ti: stored as [ti][ci]
+                                    __builtin_amdgcn_wave_barrier();
+                                    const uint2 col = *reinterpret_cast<const uint2 *>(&ext_sh[wv][ti * 8]);
+                                    unsigned cleared = 0;
+#pragma unroll
+                                    for (int ci = 0; ci < 8; ci++) {
+                                        const unsigned byte = ((ci < 4 ? col.x : col.y) >> (8 * (ci & 3))) & 0xFFu;
+                                        cleared |= ((byte >> tj) & 1u) << ci;
+                                    }
+                                    exb = ~cleared & 0xFFu;
+                                    __builtin_amdgcn_wave_barrier();
+                                }
                             }
                             if (!newim) continue;
                             const bool need = __any((exb & newim) != newim);
@@ -384,6 +456,7 @@ __global__ __launch_bounds__(256) void k_build_list(ListArgs A)
                     w.shift = s | (cost << 8);
                     A.work[w0 + k] = w;
                     atomicAdd(&s_tiles, cost);
+                    atomicAdd(&A.d->cost_hist[min(256, cost)], 1);     // for the sort of the units (no value returned)
                 }
             } else if (threadIdx.x == 0) atomicOr(&A.d->overflow, (s_start + nent > MDX_CJ_PER_SC) ? 1 : 2);
             __syncthreads();
@@ -404,28 +477,36 @@ __global__ __launch_bounds__(256) void k_build_list(ListArgs A)
 // Order the work units by descending tile count (counting sort on the cost stored next to the
 // shift index). The nonbonded kernel hands unit k, k+W, k+2W, ... to wave k, so every wave gets
 // one unit of each cost tier and the waves finish together.
-// The unit array is sparse (a fixed region per i-super-cluster, sc_nwork[] of it in use): the sort
-// visits every region, orders the units in use and stores their count.
-__global__ void k_sort_work(DevState *__restrict__ d, const NbWork *__restrict__ work, const int *__restrict__ sc_nwork,
-                            int *__restrict__ order)
+// The list builder has already counted the units per cost (DevState::cost_hist). Every block here
+// derives the first position of each cost from that histogram, counts its own slice of the sparse
+// unit array (a fixed region per i-super-cluster, sc_nwork[] of it in use), reserves a range per
+// cost with one returning atomic and scatters within the range through LDS.
+__global__ __launch_bounds__(1024) void k_sort_work(DevState *__restrict__ d, const NbWork *__restrict__ work,
+                                                    const int *__restrict__ sc_nwork, int *__restrict__ order)
 {
-    __shared__ int hist[257];
-    __shared__ int first[257];
+    __shared__ int first[257], mine[257];
     const int n = d->nsc * MDX_WORK_PER_SC;
-    for (int c = threadIdx.x; c < 257; c += blockDim.x) hist[c] = 0;
-    __syncthreads();
-    for (int k = threadIdx.x; k < n; k += blockDim.x)
-        if ((k % MDX_WORK_PER_SC) < sc_nwork[k / MDX_WORK_PER_SC]) atomicAdd(&hist[min(256, work[k].shift >> 8)], 1);
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int k0 = blockIdx.x * per, k1 = min(n, k0 + per);
+    for (int c = threadIdx.x; c < 257; c += blockDim.x) { first[c] = d->cost_hist[c]; mine[c] = 0; }
     __syncthreads();
     if (threadIdx.x == 0) {
         int run = 0;
-        for (int c = 256; c >= 0; c--) { first[c] = run; run += hist[c]; }
-        d->nwork = run;
+        for (int c = 256; c >= 0; c--) { const int h = first[c]; first[c] = run; run += h; }
+        if (blockIdx.x == 0) d->nwork = run;
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < n; k += blockDim.x)
+    for (int k = k0 + threadIdx.x; k < k1; k += blockDim.x)
+        if ((k % MDX_WORK_PER_SC) < sc_nwork[k / MDX_WORK_PER_SC]) atomicAdd(&mine[min(256, work[k].shift >> 8)], 1);
+    __syncthreads();
+    for (int c = threadIdx.x; c < 257; c += blockDim.x) {
+        const int m = mine[c];
+        mine[c] = m ? first[c] + atomicAdd(&d->cost_cursor[c], m) : 0;
+    }
+    __syncthreads();
+    for (int k = k0 + threadIdx.x; k < k1; k += blockDim.x)
         if ((k % MDX_WORK_PER_SC) < sc_nwork[k / MDX_WORK_PER_SC]) {
-            const int pos = atomicAdd(&first[min(256, work[k].shift >> 8)], 1);
+            const int pos = atomicAdd(&mine[min(256, work[k].shift >> 8)], 1);
             order[pos] = k;
         }
 }
@@ -523,7 +604,7 @@ int mdx_search(mdx_system *s)
     hipLaunchKernelGGL(k_colscan, dim3(1), dim3(1024), 0, s->stream, ncol, s->col_count, s->col_astart, s->col_scstart,
                        s->d, s->npad / 64);
     hipLaunchKernelGGL(k_fill, dim3(nbk), dim3(256), 0, s->stream, s->n, s->atom_col, s->atom_slot, s->col_astart, s->col_atoms);
-    hipLaunchKernelGGL(k_sortcol, dim3(ncol), dim3(256), 0, s->stream, s->col_count, s->col_astart, s->col_scstart,
+    hipLaunchKernelGGL(k_sortcol, dim3(ncol), dim3(1024), 0, s->stream, s->col_count, s->col_astart, s->col_scstart,
                        s->col_atoms, s->wrapped, s->x, s->lj, s->molid, s->xq_s, s->lj_s, s->perm, s->perm_src, s->shift_s,
                        s->molid_s, s->sorted_of, s->bb_lo, s->bb_hi, s->sbb_lo, s->sbb_hi, s->npad / 64);
     hipLaunchKernelGGL(k_shiftvec, dim3(1), dim3(64), 0, s->stream, s->d, s->nshift, s->shift_ijk, s->shiftvec);
@@ -532,10 +613,10 @@ int mdx_search(mdx_system *s)
     A.molid_s = s->molid_s; A.bb_lo = s->bb_lo; A.bb_hi = s->bb_hi; A.sbb_lo = s->sbb_lo; A.sbb_hi = s->sbb_hi;
     A.shiftvec = s->shiftvec; A.nshift = s->nshift; A.central = s->central_shift; A.excl_start = s->excl_start;
     A.excl_list = s->excl_list; A.cj = s->cj; A.work = s->work; A.sc_nwork = s->sc_nwork;
-    A.exclmask = s->exclmask; A.rlist = s->rlist;
+    A.exclmask = s->exclmask; A.rlist = s->rlist; A.dbg = s->dbg;
     const int nblk = s->npad / 64;
     hipLaunchKernelGGL(k_build_list, dim3(nblk), dim3(256), 0, s->stream, A);
-    hipLaunchKernelGGL(k_sort_work, dim3(1), dim3(1024), 0, s->stream, s->d, s->work, s->sc_nwork, s->work_order);
+    hipLaunchKernelGGL(k_sort_work, dim3(32), dim3(1024), 0, s->stream, s->d, s->work, s->sc_nwork, s->work_order);
     MDX_CHECK(s, hipGetLastError());
     s->steps_since_search = 0;
     return MDX_OK;
