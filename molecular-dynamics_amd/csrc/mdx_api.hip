@@ -65,9 +65,9 @@ extern "C" mdx_system *mdx_create(int device, int natoms)
     bool ok = hipStreamCreate(&s->stream) == hipSuccess &&
               hipStreamCreateWithPriority(&s->st_pme, hipStreamDefault, prio_greatest) == hipSuccess &&
               hipStreamCreateWithPriority(&s->st_bond, hipStreamDefault, prio_greatest) == hipSuccess &&
-              hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&s->ev_pme, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&s->ev_bond, hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
+              hipEventCreateWithFlags(&s->ev_pme, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
+              hipEventCreateWithFlags(&s->ev_bond, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
     const int n = natoms;
     s->ncol_cap = n / 128 + 256;
     s->npad = ((n + 63) / 64 + s->ncol_cap) * 64;
@@ -548,10 +548,11 @@ int mdx_fork(mdx_system *s)
 }
 int mdx_join(mdx_system *s)
 {
-    MDX_CHECK(s, hipEventRecord(s->ev_pme, s->st_pme));
+    if (!s->pme_signalled) MDX_CHECK(s, hipEventRecord(s->ev_pme, s->st_pme));
+    s->pme_signalled = false;
     MDX_CHECK(s, hipEventRecord(s->ev_bond, s->st_bond));
-    MDX_CHECK(s, hipStreamWaitEvent(s->stream, s->ev_pme, 0));
     MDX_CHECK(s, hipStreamWaitEvent(s->stream, s->ev_bond, 0));
+    MDX_CHECK(s, hipStreamWaitEvent(s->stream, s->ev_pme, 0));
     return MDX_OK;
 }
 
@@ -684,10 +685,9 @@ extern "C" int mdx_step(mdx_system *s, long long nsteps)
         // the leap-frog kernel leaves f cleared; only a force evaluation outside the step loop dirties it
         if (s->f_dirty) { MDX_CHECK(s, hipMemsetAsync(s->f, 0, sizeof(float) * 3 * s->n, s->stream)); s->f_dirty = false; }
         if (do_search) if ((rc = mdx_search(s))) return rc;
-        // fork before the prepare kernel: the side streams read the state and the search arrays only, so
-        // prepare -> nonbonded run back to back on the main stream without an event between them
-        if ((rc = mdx_fork(s))) return rc;
-        if ((rc = mdx_launch_prepare(s))) return rc;
+        // the side streams start when the prepare kernel completes (its completion signal is the fork event:
+        // an event recorded by a separate marker costs the main stream several microseconds)
+        if ((rc = mdx_launch_prepare(s, true))) return rc;
         // the nonbonded kernel is the critical path: enqueue it first, the side streams fill in
         if ((rc = mdx_launch_nonbonded(s, need_vir, MDX_F_NONBONDED | (s->have_pme ? MDX_F_EXCL : 0)))) return rc;
         if ((rc = mdx_launch_pme(s, need_vir))) return rc;

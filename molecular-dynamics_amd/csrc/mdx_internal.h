@@ -186,6 +186,7 @@ struct mdx_system {
     double *ener_log = nullptr; int ener_log_cap = 0; long long ener_log_count = 0;
     // timing of the dominant kernel (HIP events on this stream)
     unsigned nb_launch_seq = 0;
+    bool pme_signalled = false;        // ev_pme already attached to the last kernel of the PME chain
     bool time_nb = false; std::vector<hipEvent_t> ev_pool; std::vector<std::pair<int, int>> ev_nb;
     double nb_ms_total = 0; long long nb_launches = 0;
     void *frame_ring = nullptr;   // pinned trajectory-frame slots (runctl.hip)
@@ -205,7 +206,7 @@ struct mdx_system {
 int mdx_search(mdx_system *s);
 int mdx_fork(mdx_system *s);
 int mdx_join(mdx_system *s);
-int mdx_launch_prepare(mdx_system *s);
+int mdx_launch_prepare(mdx_system *s, bool fork = false);
 int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms);
 int mdx_launch_pme(mdx_system *s, bool energy);
 int mdx_launch_bonded(mdx_system *s, bool energy, unsigned flags);

@@ -12,6 +12,7 @@
 // (j-cluster, 8-bit i-cluster mask, exclusion-mask slot) entries plus work units of at most
 // MDX_NB_CHUNK entries for the nonbonded kernel.
 #include "mdx_internal.h"
+#include <hip/hip_ext.h>
 
 #define BIG_KEY 3.0e38f
 
@@ -549,9 +550,20 @@ __global__ void k_shiftvec(const DevState *__restrict__ d, int nshift, const int
     }
 }
 
-int mdx_launch_prepare(mdx_system *s)
+// With `fork` the kernel's own completion signal is the fork event of the side streams (an event
+// recorded by a separate marker costs the main stream several microseconds between two kernels).
+int mdx_launch_prepare(mdx_system *s, bool fork)
 {
     const int nb = (s->npad + 255) / 256;
+    if (fork) {
+        hipExtLaunchKernelGGL(k_prepare, dim3(nb), dim3(256), 0, s->stream, nullptr, s->ev_fork, 0, s->npad, s->d,
+                              (const float4 *)s->x, (const int *)s->perm, (const int *)s->perm_src, (const int *)s->shift_s,
+                              s->xq_s, s->f_s, s->nshift, (const int3 *)s->shift_ijk, s->shiftvec);
+        MDX_CHECK(s, hipGetLastError());
+        MDX_CHECK(s, hipStreamWaitEvent(s->st_pme, s->ev_fork, 0));
+        MDX_CHECK(s, hipStreamWaitEvent(s->st_bond, s->ev_fork, 0));
+        return MDX_OK;
+    }
     hipLaunchKernelGGL(k_prepare, dim3(nb), dim3(256), 0, s->stream, s->npad, s->d, s->x, s->perm, s->perm_src,
                        s->shift_s, s->xq_s, s->f_s, s->nshift, s->shift_ijk, s->shiftvec);
     MDX_CHECK(s, hipGetLastError());

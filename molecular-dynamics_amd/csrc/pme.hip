@@ -4,6 +4,7 @@
 // Grid layout: (nx, ny, nz) with z fastest; fractional coordinates s = x . inv(box) so the
 // triclinic dodecahedron needs no special casing; reciprocal vectors m = inv(box) . m'.
 #include "mdx_internal.h"
+#include <hip/hip_ext.h>
 #include <algorithm>
 #include <cstdlib>
 
@@ -342,7 +343,10 @@ int mdx_launch_pme(mdx_system *s, bool energy)
     else
         hipLaunchKernelGGL(k_pme_solve<false>, dim3(nbs), dim3(256), 0, s->st_pme, s->cgrid, s->d, s->d, K0, K1, K2, s->bmod[0], s->bmod[1], s->bmod[2], s->beta);
     if (hipfftExecC2R(s->plan_c2r, (hipfftComplex *)s->cgrid, s->grid) != HIPFFT_SUCCESS) { s->err = "hipfftExecC2R failed"; return MDX_ERR_HIP; }
-    hipLaunchKernelGGL(k_pme_gather, dim3(nb), dim3(256), 0, s->st_pme, s->n, s->x, s->d, K0, K1, K2, s->grid, s->f_pme);
+    // the completion signal of the last kernel of the chain is the event the main stream waits for
+    hipExtLaunchKernelGGL(k_pme_gather, dim3(nb), dim3(256), 0, s->st_pme, nullptr, s->ev_pme, 0, s->n, (const float4 *)s->x,
+                          (const DevState *)s->d, K0, K1, K2, (const float *)s->grid, s->f_pme);
+    s->pme_signalled = true;
     MDX_CHECK(s, hipGetLastError());
     return MDX_OK;
 }
