@@ -6,6 +6,7 @@
 // (/root/reference/mdp/em_complex.mdp:3-6) and the output cadence keys `nstxout`,
 // `nstvout`, `nstxout-compressed` (/root/reference/mdp/production.mdp:7-12) switch on in gmx mdrun.
 #include "mdx_internal.h"
+#include <hip/hip_ext.h>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -209,19 +210,24 @@ extern "C" int mdx_minimize(mdx_system *s, long long nsteps, double emtol, doubl
 }
 
 // ---------------------------------------------------------------- trajectory frames
-// A ring of pinned host slots; a capture enqueues an unpack kernel and device-to-host copies on
-// the main stream followed by an event, so the step loop keeps running while a writer thread
-// waits for the event and encodes the frame.
-__global__ __launch_bounds__(256) void k_unpack3(int n, const float4 *__restrict__ a, float *__restrict__ out)
+// A ring of pinned host slots. A capture enqueues unpack kernels into a per-slot device staging area
+// on the main stream; the device-to-host copies run on the bonded stream (idle between two steps and
+// with slack inside a step), released by the completion signal of the last unpack kernel, so the main
+// stream never waits for the DMA. A stream of their own would be the fourth of the process: with four
+// hardware queues per process it would share a queue with a compute stream and stall it (measured:
+// +130 us per step). A writer thread waits for the slot's event and encodes the frame.
+__global__ __launch_bounds__(256) void k_unpack3(int n, const float4 *__restrict__ a, float *__restrict__ out,
+                                                 const double *__restrict__ boxd, double *__restrict__ box_out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 9 && box_out) box_out[i] = boxd[i];
     if (i >= n) return;
     const float4 p = a[i];
     out[3 * i] = p.x; out[3 * i + 1] = p.y; out[3 * i + 2] = p.z;
 }
 
-struct FrameSlot { float *x = nullptr, *v = nullptr; double *box = nullptr; hipEvent_t ev = nullptr; long long step = -1; int has_v = 0; };
-struct FrameRing { std::vector<FrameSlot> slots; float *d_stage = nullptr; };
+struct FrameSlot { float *x = nullptr, *v = nullptr; double *box = nullptr; hipEvent_t ev = nullptr, ev_staged = nullptr; long long step = -1; int has_v = 0; };
+struct FrameRing { std::vector<FrameSlot> slots; float *d_stage = nullptr; double *d_box = nullptr; };
 static FrameRing *ring_of(mdx_system *s) { return (FrameRing *)s->frame_ring; }
 
 void mdx_frames_free(mdx_system *s)
@@ -233,8 +239,10 @@ void mdx_frames_free(mdx_system *s)
         if (f.v) (void)hipHostFree(f.v);
         if (f.box) (void)hipHostFree(f.box);
         if (f.ev) (void)hipEventDestroy(f.ev);
+        if (f.ev_staged) (void)hipEventDestroy(f.ev_staged);
     }
     if (r->d_stage) (void)hipFree(r->d_stage);
+    if (r->d_box) (void)hipFree(r->d_box);
     delete r;
     s->frame_ring = nullptr;
 }
@@ -253,9 +261,11 @@ extern "C" int mdx_frame_ring(mdx_system *s, int nslots)
         MDX_CHECK(s, hipHostMalloc((void **)&f.v, bytes, hipHostMallocDefault));
         MDX_CHECK(s, hipHostMalloc((void **)&f.box, sizeof(double) * 9, hipHostMallocDefault));
         MDX_CHECK(s, hipEventCreateWithFlags(&f.ev, hipEventDisableTiming));
+        MDX_CHECK(s, hipEventCreateWithFlags(&f.ev_staged, hipEventDisableTiming));
     }
     // one staging buffer per slot so that consecutive captures do not wait for each other
     MDX_CHECK(s, hipMalloc((void **)&r->d_stage, 2 * bytes * nslots));
+    MDX_CHECK(s, hipMalloc((void **)&r->d_box, sizeof(double) * 9 * nslots));
     return MDX_OK;
 }
 
@@ -268,14 +278,17 @@ extern "C" int mdx_capture_frame(mdx_system *s, int slot, int want_v)
     const int n = s->n, nb = (n + 255) / 256;
     const size_t cnt = 3 * (size_t)n;
     float *dx = r->d_stage + 2 * cnt * slot, *dv = dx + cnt;
-    hipLaunchKernelGGL(k_unpack3, dim3(nb), dim3(256), 0, s->stream, n, s->x, dx);
-    MDX_CHECK(s, hipMemcpyAsync(f.x, dx, sizeof(float) * cnt, hipMemcpyDeviceToHost, s->stream));
-    if (want_v) {
-        hipLaunchKernelGGL(k_unpack3, dim3(nb), dim3(256), 0, s->stream, n, s->v, dv);
-        MDX_CHECK(s, hipMemcpyAsync(f.v, dv, sizeof(float) * cnt, hipMemcpyDeviceToHost, s->stream));
-    }
-    MDX_CHECK(s, hipMemcpyAsync(f.box, s->d->boxd, sizeof(double) * 9, hipMemcpyDeviceToHost, s->stream));
-    MDX_CHECK(s, hipEventRecord(f.ev, s->stream));
+    double *dbox = r->d_box + 9 * slot;
+    if (want_v) hipLaunchKernelGGL(k_unpack3, dim3(nb), dim3(256), 0, s->stream, n, s->v, dv, nullptr, nullptr);
+    hipExtLaunchKernelGGL(k_unpack3, dim3(nb), dim3(256), 0, s->stream, nullptr, f.ev_staged, 0, n, (const float4 *)s->x, dx,
+                          (const double *)s->d->boxd, dbox);
+    MDX_CHECK(s, hipGetLastError());
+    hipStream_t cs = s->st_bond;
+    MDX_CHECK(s, hipStreamWaitEvent(cs, f.ev_staged, 0));
+    MDX_CHECK(s, hipMemcpyAsync(f.x, dx, sizeof(float) * cnt, hipMemcpyDeviceToHost, cs));
+    if (want_v) MDX_CHECK(s, hipMemcpyAsync(f.v, dv, sizeof(float) * cnt, hipMemcpyDeviceToHost, cs));
+    MDX_CHECK(s, hipMemcpyAsync(f.box, dbox, sizeof(double) * 9, hipMemcpyDeviceToHost, cs));
+    MDX_CHECK(s, hipEventRecord(f.ev, cs));
     f.step = s->step; f.has_v = want_v ? 1 : 0;
     return MDX_OK;
 }
