@@ -100,7 +100,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("MDX_BENCH_FORCE_DIST"))     # the latter: rehearsal of the N>1 code path on one GPU
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import mdx  # noqa: F401
@@ -133,7 +134,7 @@ def main():
         pipe = FramePipeline(e, 8, xtc, None, None, dt, 0.0, nthreads=args.encoders)
     e.enable_kernel_timing(True)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
     if nst_xtc:
@@ -152,7 +153,7 @@ def main():
     if pipe is not None:
         pipe.finish()
         xtc.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     xtc_frames = xtc.frames if xtc is not None else 0
@@ -164,7 +165,7 @@ def main():
     nb_ms, nb_launches = e.kernel_timing()
     e.enable_kernel_timing(False)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed_max = float(tmax.item())
     frames = e.pop_energy_frames()
@@ -176,7 +177,7 @@ def main():
         dF = ensemble.jarzynski_free_energy(allw, 300.0)
         smd = dict(samples=int(len(rec)), replicas=int(allw.shape[0]), final_distance=float(rec[-1, 1]) if len(rec) else None,
                    jarzynski_dF_final=float(dF[-1]) if len(dF) else None)
-    elif world > 1:
+    elif use_dist:
         # replicas only: one tiny RCCL all-gather of the final potential energies (no data-path collective)
         allw = ensemble.gather_work(np.array([frames[-1, 2 + eng.E["POT"]]]))
     ns_day = dt * args.steps * 86400.0 / elapsed_max / 1000.0 * world
@@ -237,7 +238,7 @@ def main():
                                              "own CPU restatement, not GROMACS" % (args.cpu_steps, s.natoms, threads, wall)}
         print(json.dumps(out), flush=True)
     e.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -12,6 +12,7 @@
 // with Lorentz-Berthelot sigma/eps from per-atom (sigma/2, 2 sqrt(eps)) so no type table gather.
 #include "mdx_internal.h"
 #include <cstdlib>
+#include <type_traits>
 #include <cstddef>
 
 struct NbArgs {
@@ -29,6 +30,7 @@ struct NbArgs {
     float inv_rc6;               // 1/rc^6
     int central;                 // index of the zero lattice shift
     int do_pairs, do_excl;       // evaluate listed pairs / the Ewald correction of excluded pairs
+    int dbg;                     // diagnostic ablation bits (timing experiments only)
 };
 
 // Cross-lane adds inside groups of 8 consecutive lanes as DPP moves (no LDS crossbar traffic).
@@ -135,66 +137,78 @@ __device__ __forceinline__ void nb_body(const NbArgs &A)
             if (do_excl) live |= ~ex & 0xFFu;
             if (is_central && (cj >> 3) == sci && tj <= ti) live &= ~(1u << (cj & 7));
             float fjx = 0.0f, fjy = 0.0f, fjz = 0.0f;
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                if (imask & (1u << c)) {
-                    const float dx = xi[c] - pj.x, dy = yi[c] - pj.y, dz = zi[c] - pj.z;
-                    float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                    const bool within = (r2 < rc2) && ((live >> c) & 1u);
-                    // the list is built with a buffer: an 8x8 tile none of whose pairs is inside the
-                    // cutoff right now costs only the distance test (wave-uniform skip)
-                    if (__builtin_amdgcn_ballot_w64(within) == 0ull) continue;
-                    const bool listed = (ex >> c) & 1u;          // false: excluded pair, Ewald correction only
-                    r2 = fmaxf(r2, 1.0e-12f);
-                    const float rinv = __frsqrt_rn(r2);
-                    const float rinv2 = rinv * rinv;
-                    const float sg = hsi[c] + lj.x;
-                    const float e4 = sei[c] * lj.y;
-                    const float s2 = sg * sg * rinv2;
-                    const float s6 = s2 * s2 * s2;
-                    const float t6 = e4 * s6;
-                    float fs = t6 * fmaf(12.0f, s6, -6.0f);
-                    const float qq = qi[c] * pj.w;
-                    float erfc_br = 0.0f, e_ex = 0.0f;
-                    if (ENERGY) {
-                        const float br = beta * r2 * rinv;
-                        const float ex2 = __builtin_amdgcn_exp2f(nb2l2e * r2);
-                        erfc_br = ex2 * mdx_erfcx_poly(br);
-                        fs = fmaf(qq * rinv, fmaf(MDX_2_SQRTPI * br, ex2, erfc_br), fs);
-                        fs *= rinv2;
-                        if (slot) {
-                            // tiles that hold excluded pairs (wave-uniform test): E = -qq erf(br)/r through the
-                            // cancellation-free g: erf(z)/z = g w + 2/sqrt(pi) exp(-w)
-                            const float w_ = beta2 * r2;
-                            const float g = mdx_pmecorr(w_);
-                            fs = listed ? fs : -qq * beta3 * g;
-                            e_ex = -qq * beta * fmaf(g, w_, MDX_2_SQRTPI * ex2);
-                        }
-                    } else {
-                        // (t6 (12 s6 - 6) + qq/r) / r^2 - qq beta^3 g; an excluded pair keeps only the last term
-                        fs = fmaf(qq, rinv, fs) * rinv2;
-                        if (slot) fs = listed ? fs : 0.0f;      // wave-uniform: most tiles hold no excluded pair
-                        fs = fmaf(-qq * beta3, mdx_pmecorr(beta2 * r2), fs);
+            // One 8x8 tile: i-cluster c against the j-cluster. GENERAL tiles look at the exclusion and
+            // liveness bits; the others (no mask slot, not a cluster with itself: the large majority, and
+            // a wave-uniform property of the entry) are plain cutoff tests, about ten VALU instructions
+            // shorter. The 1e-12 inside r2 keeps a filler atom, which sits exactly on a real one, finite.
+            auto tile = [&](auto general_tag, const int c) {
+                constexpr bool GENERAL = decltype(general_tag)::value;
+                const float dx = xi[c] - pj.x, dy = yi[c] - pj.y, dz = zi[c] - pj.z;
+                const float r2 = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, 1.0e-12f)));
+                bool within = r2 < rc2;
+                if (GENERAL) within = within && ((live >> c) & 1u);
+                // the list is built with a buffer: an 8x8 tile none of whose pairs is inside the
+                // cutoff right now costs only the distance test (wave-uniform skip)
+                if (__builtin_amdgcn_ballot_w64(within) == 0ull) return;
+                const bool listed = GENERAL ? (((ex >> c) & 1u) != 0u) : true;   // false: excluded pair, Ewald correction only
+                const float rinv = __frsqrt_rn(r2);
+                const float rinv2 = rinv * rinv;
+                const float sg = hsi[c] + lj.x;
+                const float e4 = sei[c] * lj.y;
+                const float s2 = sg * sg * rinv2;
+                const float s6 = s2 * s2 * s2;
+                const float t6 = e4 * s6;
+                float fs = t6 * fmaf(12.0f, s6, -6.0f);
+                const float qq = qi[c] * pj.w;
+                float erfc_br = 0.0f, e_ex = 0.0f;
+                if (ENERGY) {
+                    const float br = beta * r2 * rinv;
+                    const float ex2 = __builtin_amdgcn_exp2f(nb2l2e * r2);
+                    erfc_br = ex2 * mdx_erfcx_poly(br);
+                    fs = fmaf(qq * rinv, fmaf(MDX_2_SQRTPI * br, ex2, erfc_br), fs);
+                    fs *= rinv2;
+                    if (GENERAL && slot) {
+                        // tiles that hold excluded pairs (wave-uniform test): E = -qq erf(br)/r through the
+                        // cancellation-free g: erf(z)/z = g w + 2/sqrt(pi) exp(-w)
+                        const float w_ = beta2 * r2;
+                        const float g = mdx_pmecorr(w_);
+                        fs = listed ? fs : -qq * beta3 * g;
+                        e_ex = -qq * beta * fmaf(g, w_, MDX_2_SQRTPI * ex2);
                     }
-                    fs = within ? fs : 0.0f;
-                    const float fx = fs * dx, fy = fs * dy, fz = fs * dz;
-                    fix[c] += fx; fiy[c] += fy; fiz[c] += fz;
-                    fjx -= fx; fjy -= fy; fjz -= fz;
-                    if (ENERGY) {
-                        if (within && listed) {
-                            npair++;
-                            if (e4 != 0.0f) nlj++;
-                            const float c2 = sg * sg * (1.0f / rc2);
-                            const float c6 = c2 * c2 * c2;
-                            elj += t6 * (s6 - 1.0f) - e4 * c6 * (c6 - 1.0f);
-                            ecoul += qq * (erfc_br * rinv - A.c_rf_shift);
-                        } else if (within) {
-                            eexcl += e_ex;
-                        }
-                        vxx = fmaf(dx, fx, vxx); vxy = fmaf(dx, fy, vxy); vxz = fmaf(dx, fz, vxz);
-                        vyy = fmaf(dy, fy, vyy); vyz = fmaf(dy, fz, vyz); vzz = fmaf(dz, fz, vzz);
-                    }
+                } else {
+                    // (t6 (12 s6 - 6) + qq/r) / r^2 - qq beta^3 g; an excluded pair keeps only the last term
+                    fs = fmaf(qq, rinv, fs) * rinv2;
+                    if (GENERAL && slot) fs = listed ? fs : 0.0f;      // wave-uniform: few tiles hold an excluded pair
+                    fs = fmaf(-qq * beta3, mdx_pmecorr(beta2 * r2), fs);
                 }
+                fs = within ? fs : 0.0f;
+                const float fx = fs * dx, fy = fs * dy, fz = fs * dz;
+                fix[c] += fx; fiy[c] += fy; fiz[c] += fz;
+                fjx -= fx; fjy -= fy; fjz -= fz;
+                if (ENERGY) {
+                    if (within && listed) {
+                        npair++;
+                        if (e4 != 0.0f) nlj++;
+                        const float c2 = sg * sg * (1.0f / rc2);
+                        const float c6 = c2 * c2 * c2;
+                        elj += t6 * (s6 - 1.0f) - e4 * c6 * (c6 - 1.0f);
+                        ecoul += qq * (erfc_br * rinv - A.c_rf_shift);
+                    } else if (within) {
+                        eexcl += e_ex;
+                    }
+                    vxx = fmaf(dx, fx, vxx); vxy = fmaf(dx, fy, vxy); vxz = fmaf(dx, fz, vxz);
+                    vyy = fmaf(dy, fy, vyy); vyz = fmaf(dy, fz, vyz); vzz = fmaf(dz, fz, vzz);
+                }
+            };
+            const bool general = slot != 0u || !do_pairs || (is_central && (cj >> 3) == sci);    // wave-uniform
+            if (!general) {
+#pragma unroll
+                for (int c = 0; c < 8; c++)
+                    if (imask & (1u << c)) tile(std::false_type{}, c);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; c++)
+                    if (imask & (1u << c)) tile(std::true_type{}, c);
             }
             fjx = sum8(fjx); fjy = sum8(fjy); fjz = sum8(fjz);
             const int ja3 = 3 * (cj * 8 + tj);
@@ -206,9 +220,9 @@ __device__ __forceinline__ void nb_body(const NbArgs &A)
                 const float cur = (ti == 3) ? fjx : ((ti == 4) ? fjy : fjz);
                 const float val = (ti < 3) ? hold : cur;
                 const int addr = (ti < 3) ? hold_addr : ja3 + ti - 3;
-                if (ti < 6) atomicAdd(&A.f_s[addr], val);
+                if (ti < 6 && !(A.dbg & 0x20000)) atomicAdd(&A.f_s[addr], val);
             } else {
-                if (ti < 3) atomicAdd(&A.f_s[ja3 + ti], (ti == 0) ? fjx : ((ti == 1) ? fjy : fjz));
+                if (ti < 3 && !(A.dbg & 0x20000)) atomicAdd(&A.f_s[ja3 + ti], (ti == 0) ? fjx : ((ti == 1) ? fjy : fjz));
             }
         }
 #pragma unroll
@@ -217,7 +231,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A)
             ax += dpp_row_ror8(ax); ay += dpp_row_ror8(ay); az += dpp_row_ror8(az);
             ax += __shfl_xor(ax, 16, 64); ay += __shfl_xor(ay, 16, 64); az += __shfl_xor(az, 16, 64);
             ax += __shfl_xor(ax, 32, 64); ay += __shfl_xor(ay, 32, 64); az += __shfl_xor(az, 32, 64);
-            if (tj < 3) {
+            if (tj < 3 && !(A.dbg & 0x40000)) {
                 const float val = (tj == 0) ? ax : ((tj == 1) ? ay : az);
                 atomicAdd(&A.f_s[3 * ((sci * 8 + c) * 8 + ti) + tj], val);
             }
@@ -260,6 +274,7 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
 {
     NbArgs A;
     A.central = s->central_shift;
+    A.dbg = s->dbg;
     A.do_pairs = (terms & MDX_F_NONBONDED) ? 1 : 0;
     A.do_excl = ((terms & MDX_F_EXCL) && s->beta > 0.0f) ? 1 : 0;
     if (!A.do_pairs && !A.do_excl) return MDX_OK;
