@@ -115,7 +115,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A)
         int cj_n = __builtin_amdgcn_readlane(myent.cj, 0);
         float4 pj_n = A.xq_s[cj_n * 8 + tj];
         float2 lj_n = A.lj_s[cj_n * 8 + tj];
-        float hold = 0.0f; int hold_addr = 0;
+        float hold = 0.0f; int hold_addr = 0; bool hold_did = false;
         for (int e = 0; e < count; e++) {
             const int cj = cj_n;
             const float4 pj = pj_n;
@@ -137,6 +137,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A)
             if (do_excl) live |= ~ex & 0xFFu;
             if (is_central && (cj >> 3) == sci && tj <= ti) live &= ~(1u << (cj & 7));
             float fjx = 0.0f, fjy = 0.0f, fjz = 0.0f;
+            bool did = false;           // wave-uniform: some tile of this entry had a pair inside the cutoff
             // One 8x8 tile: i-cluster c against the j-cluster. GENERAL tiles look at the exclusion and
             // liveness bits; the others (no mask slot, not a cluster with itself: the large majority, and
             // a wave-uniform property of the entry) are plain cutoff tests, about ten VALU instructions
@@ -150,6 +151,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A)
                 // the list is built with a buffer: an 8x8 tile none of whose pairs is inside the
                 // cutoff right now costs only the distance test (wave-uniform skip)
                 if (__builtin_amdgcn_ballot_w64(within) == 0ull) return;
+                did = true;
                 const bool listed = GENERAL ? (((ex >> c) & 1u) != 0u) : true;   // false: excluded pair, Ewald correction only
                 const float rinv = __frsqrt_rn(r2);
                 const float rinv2 = rinv * rinv;
@@ -210,19 +212,24 @@ __device__ __forceinline__ void nb_body(const NbArgs &A)
                 for (int c = 0; c < 8; c++)
                     if (imask & (1u << c)) tile(std::true_type{}, c);
             }
-            fjx = sum8(fjx); fjy = sum8(fjy); fjz = sum8(fjz);
+            // an entry none of whose tiles had a pair inside the cutoff has no j-force to reduce or add
+            if (did) { fjx = sum8(fjx); fjy = sum8(fjy); fjz = sum8(fjz); }
             const int ja3 = 3 * (cj * 8 + tj);
             if (((e & 1) == 0) && (e + 1 < count)) {
                 // keep this cluster's components on lanes ti = 0..2 until the next one is ready
                 hold = (ti == 0) ? fjx : ((ti == 1) ? fjy : fjz);
                 hold_addr = ja3 + ti;
+                hold_did = did;
             } else if (e & 1) {
-                const float cur = (ti == 3) ? fjx : ((ti == 4) ? fjy : fjz);
-                const float val = (ti < 3) ? hold : cur;
-                const int addr = (ti < 3) ? hold_addr : ja3 + ti - 3;
-                if (ti < 6 && !(A.dbg & 0x20000)) atomicAdd(&A.f_s[addr], val);
+                if (did || hold_did) {
+                    const float cur = (ti == 3) ? fjx : ((ti == 4) ? fjy : fjz);
+                    const float val = (ti < 3) ? hold : cur;
+                    const int addr = (ti < 3) ? hold_addr : ja3 + ti - 3;
+                    const bool mine = (ti < 3) ? hold_did : (did && ti < 6);
+                    if (mine && !(A.dbg & 0x20000)) atomicAdd(&A.f_s[addr], val);
+                }
             } else {
-                if (ti < 3 && !(A.dbg & 0x20000)) atomicAdd(&A.f_s[ja3 + ti], (ti == 0) ? fjx : ((ti == 1) ? fjy : fjz));
+                if (did && ti < 3 && !(A.dbg & 0x20000)) atomicAdd(&A.f_s[ja3 + ti], (ti == 0) ? fjx : ((ti == 1) ? fjy : fjz));
             }
         }
 #pragma unroll
