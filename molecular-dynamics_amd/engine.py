@@ -128,14 +128,119 @@ def c6_average(sigma, eps):
 
 
 def verlet_rlist(rc, nstlist, dt, temperature=300.0, min_mass=1.008, water_constrained=True):
-    """Pair-list radius: rc plus a buffer that covers the relative displacement of two light
-    particles over the list lifetime (6 sigma of the ballistic Gaussian estimate, floored at
-    0.05 nm and capped at 0.25 nm). Stands in for GROMACS' `verlet-buffer-tolerance` estimate
-    (/root/reference/mdp/npt_complex.mdp:32); the engine treats `nstlist` as a hint like mdrun."""
+    """Pair-list radius without knowledge of the system: rc plus a buffer that covers the relative
+    displacement of two light particles over the list lifetime (6 sigma of the ballistic Gaussian
+    estimate, floored at 0.05 nm and capped at 0.25 nm). `verlet_buffer_rlist` is the estimate the
+    engine uses when it has the topology."""
     m_eff = 4.0 * min_mass if water_constrained else min_mass   # constrained H moves with its heavy atom
     sig1 = np.sqrt(U.BOLTZ * temperature / m_eff) * (nstlist - 1) * dt
     buf = 6.0 * np.sqrt(2.0) * sig1 * 0.5
     return float(rc + min(0.25, max(0.05, buf)))
+
+
+def _displacement_variance(sysm, kT_t2):
+    """Per atom <dx^2> per dimension after a list lifetime t (kT_t2 = kT t^2). Free atoms: kT t^2 / m.
+    An atom held by constraints moves with its rigid group of mass M (kT t^2 / M, three directions)
+    and swings about the group's centre on an arm a = b (M - m) / M of the constraint length b, which
+    displaces it in two directions only and by no more than the arm allows: with x = kT t^2 (M - m) /
+    (m M a^2) the swing variance is a^2 x / (1 + x/3 + 2 x^2/45), entering with weight 2/3."""
+    m = np.maximum(np.asarray(sysm.mass, dtype=np.float64), 1e-3)
+    M = m.copy()
+    arm_len = np.zeros_like(m)
+    if len(sysm.constraints):
+        c = np.asarray(sysm.constraints)
+        b = np.asarray(sysm.constraint_len, dtype=np.float64)
+        np.add.at(M, c[:, 0], m[c[:, 1]])
+        np.add.at(M, c[:, 1], m[c[:, 0]])
+        np.maximum.at(arm_len, c[:, 0], b)
+        np.maximum.at(arm_len, c[:, 1], b)
+    if len(sysm.settles):
+        w3 = np.asarray(sysm.settles)
+        tot = m[w3].sum(1)
+        for k in range(3):
+            M[w3[:, k]] = tot
+        arm_len[w3.ravel()] = float(sysm.settle_doh)
+    frac = (M - m) / M
+    var = kT_t2 / M
+    con = (M > m) & (arm_len > 0)
+    arm2 = (arm_len * frac) ** 2
+    x = np.where(con, kT_t2 * frac / m / np.maximum(arm2, 1e-30), 0.0)
+    var = var + np.where(con, (2.0 / 3.0) * arm2 * x / (1.0 + x / 3.0 + 2.0 * x * x / 45.0), 0.0)
+    return var
+
+
+def _drift_model(sysm, rc, beta, nstlist, dt, temperature, volume=None):
+    """Everything of the drift estimate that does not depend on the list radius; returns f(rlist)."""
+    from math import erfc as _erfc
+    from scipy.special import erfc as _verfc
+    n = sysm.natoms
+    if volume is None:
+        b = np.asarray(sysm.box, dtype=np.float64)
+        volume = abs(np.linalg.det(b.reshape(3, 3))) if b.size == 9 else float(np.prod(b[:3]))
+    t = max(nstlist - 1, 0) * dt
+    w = _displacement_variance(sysm, U.BOLTZ * temperature * t * t)
+    key = np.stack([np.round(np.asarray(sysm.charge, dtype=np.float64), 2), np.round(np.asarray(sysm.sigma, dtype=np.float64), 3),
+                    np.round(np.asarray(sysm.eps, dtype=np.float64), 3), np.round(w, 5)], 1)
+    uniq, cnt = np.unique(key, axis=0, return_counts=True)
+    q, sg, ep, wt = uniq[:, 0], uniq[:, 1], uniq[:, 2], uniq[:, 3]
+    sij = 0.5 * (sg[:, None] + sg[None, :]); eij = np.sqrt(ep[:, None] * ep[None, :])
+    A = 4.0 * eij * sij ** 12; B = 4.0 * eij * sij ** 6
+    qq = U.ONE_4PI_EPS0 * q[:, None] * q[None, :]
+    r = float(rc)
+    d1 = -12.0 * A / r ** 13 + 6.0 * B / r ** 7
+    d2 = 156.0 * A / r ** 14 - 42.0 * B / r ** 8
+    d3 = -2184.0 * A / r ** 15 + 336.0 * B / r ** 9
+    if beta > 0.0:
+        ex = 2.0 * beta / np.sqrt(np.pi) * np.exp(-beta * beta * r * r); ec = _erfc(beta * r)
+        g1 = -ec / r ** 2 - ex / r
+        g2 = 2.0 * ec / r ** 3 + ex * (2.0 / r ** 2 + 2.0 * beta ** 2)
+        g3 = -6.0 * ec / r ** 4 - ex * (6.0 / r ** 3 + 4.0 * beta ** 2 / r + 4.0 * beta ** 4 * r)
+    else:                       # plain shifted Coulomb
+        g1, g2, g3 = -1.0 / r ** 2, 2.0 / r ** 3, -6.0 / r ** 4
+    d1 = d1 + qq * g1; d2 = d2 + qq * g2; d3 = d3 + qq * g3
+    s2 = np.maximum(wt[:, None] + wt[None, :], 1e-30)
+    s = np.sqrt(s2)
+    weight = 0.5 * cnt[:, None] * (cnt[None, :] / volume) * 4.0 * np.pi / n / (max(nstlist, 1) * dt)
+
+    def drift(rlist):
+        rb = max(float(rlist) - r, 0.0)
+        x = rb / s
+        G = np.exp(-0.5 * x * x) / np.sqrt(2.0 * np.pi)
+        E = 0.5 * _verfc(x / np.sqrt(2.0))
+        c1 = rb * s * G - (rb * rb + s2) * E
+        c2 = s * (rb * rb + 2.0 * s2) * G - rb * (rb * rb + 3.0 * s2) * E
+        c3 = rb * s * (rb * rb + 5.0 * s2) * G - (rb ** 4 + 6.0 * rb * rb * s2 + 3.0 * s2 * s2) * E
+        per_pair = np.abs(d1 * c1) / 2.0 + np.abs(d2 * c2) / 6.0 + np.abs(d3 * c3) / 24.0
+        return float((weight * float(rlist) ** 2 * per_pair).sum())
+    return drift
+
+
+def verlet_buffer_drift(sysm, rc, rlist, beta, nstlist, dt, temperature, volume=None):
+    """Estimated energy drift (kJ/mol/ps per atom) caused by pairs that start beyond `rlist` and
+    come within `rc` during a list lifetime: the Gaussian-displacement estimate behind
+    `verlet-buffer-tolerance` (/root/reference/mdp/production.mdp:23, npt_complex.mdp:32; GROMACS
+    manual, "Energy drift and pair-list buffering"). Per pair type the shifted potential is expanded
+    to third order around rc and averaged over the displacement distribution after nstlist - 1
+    steps; absolute values of the three terms are summed, and the error at the end of the lifetime
+    is charged to the whole lifetime, so the estimate errs on the large side. (GROMACS further
+    lowers the radius for the pairs a cluster list holds beyond it; that bonus is not taken here.)"""
+    return _drift_model(sysm, rc, beta, nstlist, dt, temperature, volume)(rlist)
+
+
+def verlet_buffer_rlist(sysm, rc, beta, nstlist, dt, temperature=300.0, tolerance=0.005, volume=None):
+    """Smallest pair-list radius (1e-3 nm steps, at most rc + 0.5) whose estimated drift stays within
+    `verlet-buffer-tolerance` (kJ/mol/ps per atom, GROMACS' default 0.005)."""
+    drift = _drift_model(sysm, rc, beta, nstlist, dt, temperature, volume)
+    lo, hi = 0.0, 0.5
+    if drift(rc + hi) > tolerance:
+        return float(rc + hi)
+    for _ in range(24):
+        mid = 0.5 * (lo + hi)
+        if drift(rc + mid) > tolerance:
+            lo = mid
+        else:
+            hi = mid
+    return float(round(rc + np.ceil(hi * 1000.0) / 1000.0, 4))
 
 
 class Engine:
@@ -145,7 +250,8 @@ class Engine:
                  fourierspacing=0.16, grid=None, dt=0.002, nstcalcenergy=100, nstcomm=100, device=0,
                  tc_groups=None, ref_t=None, tau_t=None, nsttcouple=10, seed=1,
                  pcoupl=0, tau_p=2.0, ref_p=1.0, compressibility=4.5e-5, nstpcouple=10,
-                 dispcorr=0, lincs_order=4, lincs_iter=1, refcoord_scaling=0, use_posres=False, beta=None):
+                 dispcorr=0, lincs_order=4, lincs_iter=1, refcoord_scaling=0, use_posres=False, beta=None,
+                 verlet_buffer_tolerance=0.005):
         self.lib = load_library()
         self.sys = sysm
         n = sysm.natoms
@@ -157,7 +263,10 @@ class Engine:
         self.beta = float(beta) if beta is not None else U.ewald_beta(rc, ewald_rtol)
         self.dt = float(dt)
         if rlist is None:
-            rlist = verlet_rlist(rc, nstlist, dt)
+            # `verlet-buffer-tolerance`: the list radius follows from the drift estimate, as in grompp/mdrun
+            t_ref = max([float(x) for x in ref_t]) if ref_t is not None and len(ref_t) else 300.0
+            rlist = verlet_buffer_rlist(sysm, rc, self.beta if pme else 0.0, nstlist, dt, max(t_ref, 1.0),
+                                        float(verlet_buffer_tolerance))
         self.rlist = float(rlist)
         # T-coupling groups
         tcg = np.zeros(n, dtype=np.int32)

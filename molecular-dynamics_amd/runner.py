@@ -437,7 +437,9 @@ def mdrun(argv, out=sys.stdout, err=sys.stderr) -> int:
             nstpcouple=nstpc, dispcorr={"no": 0, "ener": 1, "enerpres": 2}[m.s("dispcorr").lower()],
             lincs_order=m.i("lincs_order"), lincs_iter=m.i("lincs_iter"),
             refcoord_scaling={"no": 0, "all": 1, "com": 2}[m.s("refcoord_scaling").lower()],
-            use_posres=bool(meta.get("use_posres")))
+            use_posres=bool(meta.get("use_posres")),
+            rlist=(max(m.f("rlist"), rc_) if m.f("verlet_buffer_tolerance") <= 0 else None),
+            verlet_buffer_tolerance=m.f("verlet_buffer_tolerance"))
     except (MdxError, OSError) as e:
         err.write(f"\nProgram:     gmx mdrun ({PROGRAM})\n\nFatal error:\n{e}\n")
         return 1

@@ -71,6 +71,29 @@ def test_pseudo_complex_topology(small_complex):
     assert o["e_lj"] < 0 and np.abs(o["f"]).max() < 5e3
 
 
+def test_verlet_buffer_estimate():
+    """Pair-list radius from `verlet-buffer-tolerance` (/root/reference/mdp/production.mdp:23): grows with the
+    list lifetime and the temperature, shrinks with a looser tolerance, and meets the tolerance it was asked for."""
+    from mdx import synth, units as U
+    s = synth.pseudo_complex(d=6.0)
+    beta = U.ewald_beta(1.0, 1e-5)
+    r10 = eng.verlet_buffer_rlist(s, 1.0, beta, 10, 0.002, 300.0)
+    r20 = eng.verlet_buffer_rlist(s, 1.0, beta, 20, 0.002, 300.0)
+    r40 = eng.verlet_buffer_rlist(s, 1.0, beta, 40, 0.002, 300.0)
+    assert 1.0 < r10 < r20 < r40 <= 1.5
+    assert 1.02 < r10 < 1.06 and 1.06 < r20 < 1.13          # water at 300 K, 2 fs
+    assert eng.verlet_buffer_rlist(s, 1.0, beta, 20, 0.002, 300.0, tolerance=0.05) < r20
+    assert eng.verlet_buffer_rlist(s, 1.0, beta, 20, 0.002, 400.0) > r20
+    assert eng.verlet_buffer_rlist(s, 1.0, beta, 1, 0.002, 300.0) <= 1.001     # a list rebuilt every step needs no buffer
+    assert eng.verlet_buffer_drift(s, 1.0, r20, beta, 20, 0.002, 300.0) <= 0.005
+    assert eng.verlet_buffer_drift(s, 1.0, r20 - 0.005, beta, 20, 0.002, 300.0) > 0.005
+    # constrained hydrogens swing on a short arm: their displacement saturates, a free atom's does not
+    kt2 = U.BOLTZ * 300.0 * 0.1 ** 2
+    var = eng._displacement_variance(s, kt2)
+    h = s.settles[0, 1]
+    assert var[h] < kt2 / s.mass[h] and var[h] > kt2 / s.mass[s.settles[0]].sum()
+
+
 def test_rlist_and_grid_helpers():
     import importlib
     U = importlib.import_module("molecular-dynamics_amd.units")
