@@ -112,24 +112,30 @@ __device__ __forceinline__ void nb_body(const NbArgs &A)
             hsi[c] = l.x; sei[c] = l.y;
             fix[c] = 0.0f; fiy[c] = 0.0f; fiz[c] = 0.0f;
         }
+        // Software pipeline over the entries: j-atoms and exclusion mask are requested one entry ahead
         int cj_n = __builtin_amdgcn_readlane(myent.cj, 0);
         float4 pj_n = A.xq_s[cj_n * 8 + tj];
         float2 lj_n = A.lj_s[cj_n * 8 + tj];
+        unsigned mk_n = (unsigned)__builtin_amdgcn_readlane((int)myent.mask, 0);
+        unsigned ex_n = 0xFFu;
+        if (mk_n >> 8) ex_n = A.exclmask[(size_t)(mk_n >> 8) * 64 + lane];
         float hold = 0.0f; int hold_addr = 0; bool hold_did = false;
         for (int e = 0; e < count; e++) {
             const int cj = cj_n;
             const float4 pj = pj_n;
             const float2 lj = lj_n;
-            const unsigned mk = (unsigned)__builtin_amdgcn_readlane((int)myent.mask, e);
+            const unsigned mk = mk_n;
+            const unsigned ex = ex_n;
             if (e + 1 < count) {
                 cj_n = __builtin_amdgcn_readlane(myent.cj, e + 1);
                 pj_n = A.xq_s[cj_n * 8 + tj];
                 lj_n = A.lj_s[cj_n * 8 + tj];
+                mk_n = (unsigned)__builtin_amdgcn_readlane((int)myent.mask, e + 1);
+                ex_n = 0xFFu;
+                if (mk_n >> 8) ex_n = A.exclmask[(size_t)(mk_n >> 8) * 64 + lane];
             }
             const unsigned imask = mk & 0xFFu;
             const unsigned slot = mk >> 8;
-            unsigned ex = 0xFFu;
-            if (slot) ex = A.exclmask[(size_t)slot * 64 + lane];
             // `live` bit c: this lane's pair with i-cluster c is evaluated at all. In the tile of a
             // cluster with itself only tj > ti is (each pair once, no self pair); listed pairs need
             // do_pairs, excluded pairs need do_excl.
