@@ -157,8 +157,8 @@ __global__ __launch_bounds__(256) void k_posres(int n, const int *__restrict__ i
 #define LAUNCH_EV(kern, n, ...)                                                                     \
     if ((n) > 0) {                                                                                  \
         const int nb_ = ((n) + 255) / 256;                                                          \
-        if (energy) hipLaunchKernelGGL(kern<true>, dim3(nb_), dim3(256), 0, s->st_bond, n, __VA_ARGS__); \
-        else hipLaunchKernelGGL(kern<false>, dim3(nb_), dim3(256), 0, s->st_bond, n, __VA_ARGS__);   \
+        if (energy) hipLaunchKernelGGL(kern<true>, dim3(nb_), dim3(256), 0, (s->bond_on_main ? s->stream : s->st_bond), n, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kern<false>, dim3(nb_), dim3(256), 0, (s->bond_on_main ? s->stream : s->st_bond), n, __VA_ARGS__);   \
     }
 
 int mdx_launch_bonded(mdx_system *s, bool energy, unsigned flags)

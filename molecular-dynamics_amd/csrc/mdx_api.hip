@@ -116,7 +116,7 @@ extern "C" void mdx_destroy(mdx_system *s)
                      s->col_count, s->col_astart, s->col_scstart, s->col_atoms, s->atom_col, s->atom_slot, s->wrapped, s->cj, s->work, s->work_order, s->sc_nwork,
                      s->exclmask, s->shift_ijk, s->shiftvec, s->bond_ij, s->bond_p, s->angle_ijk, s->angle_p, s->dih_ijkl, s->dih_p,
                      s->pair_ij, s->pair_p, s->posres_idx, s->posres_ref, s->posres_k, s->settle_idx, s->cons_ij, s->cons_len,
-                     s->comp_start, s->d_tc, s->pull_idx[0], s->pull_idx[1], s->d };
+                     s->comp_start, s->d_tc, s->pull_idx[0], s->pull_idx[1], s->gtab, s->d };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (s->h) (void)hipHostFree(s->h);
     if (s->ener_log) (void)hipHostFree(s->ener_log);
@@ -326,8 +326,24 @@ extern "C" int mdx_set_constraints(mdx_system *s, int n, const int *idx, const f
 extern "C" int mdx_set_nonbonded(mdx_system *s, float rc, float rlist, float beta, int nstlist)
 {
     ARG_CHECK(s, rc > 0 && rlist >= rc && beta >= 0 && nstlist >= 1, "mdx_set_nonbonded: need rc > 0, rlist >= rc, nstlist >= 1");
+    (void)hipSetDevice(s->device);
     s->rc = rc; s->rlist = rlist; s->beta = beta; s->nstlist = nstlist;
     s->steps_since_search = 1 << 30;
+    // g(w) = (erf(z)/z - 2/sqrt(pi) exp(-w)) / w, w = z^2, on MDX_GTAB_N intervals of r^2 in [0, rc^2]
+    std::vector<float2> tab(MDX_GTAB_N);
+    const double wmax = (double)beta * beta * rc * rc;
+    auto g = [](double w) {
+        const double c = 1.1283791670955126;   // 2/sqrt(pi)
+        if (w < 0.05) return c * (2.0 / 3.0 + w * (-0.4 + w * (1.0 / 7.0 + w * (-1.0 / 27.0 + w * (1.0 / 132.0 - w / 780.0)))));
+        const double z = sqrt(w);
+        return (erf(z) / z - c * exp(-w)) / w;
+    };
+    for (int k = 0; k < MDX_GTAB_N; k++) {
+        const double g0 = g(wmax * k / MDX_GTAB_N), g1 = g(wmax * (k + 1) / MDX_GTAB_N);
+        tab[k] = make_float2((float)g0, (float)(g1 - g0));
+    }
+    if (!s->gtab) MDX_CHECK(s, hipMalloc((void **)&s->gtab, sizeof(float2) * MDX_GTAB_N));
+    MDX_CHECK(s, hipMemcpy(s->gtab, tab.data(), sizeof(float2) * MDX_GTAB_N, hipMemcpyHostToDevice));
     return MDX_OK;
 }
 
@@ -665,6 +681,7 @@ extern "C" int mdx_step(mdx_system *s, long long nsteps)
         MDX_CHECK(s, hipStreamSynchronize(s->stream));
         s->pull_reset_pending = false;
     }
+    bool forked_early = false;
     for (long long it = 0; it < nsteps; it++) {
         const long long step = s->step;
         const bool do_search = s->steps_since_search >= s->nstlist;
@@ -687,10 +704,11 @@ extern "C" int mdx_step(mdx_system *s, long long nsteps)
         if (do_search) if ((rc = mdx_search(s))) return rc;
         // the side streams start when the prepare kernel completes (its completion signal is the fork event:
         // an event recorded by a separate marker costs the main stream several microseconds)
-        if ((rc = mdx_launch_prepare(s, true))) return rc;
+        if ((rc = mdx_launch_prepare(s, !forked_early))) return rc;
         // the nonbonded kernel is the critical path: enqueue it first, the side streams fill in
         if ((rc = mdx_launch_nonbonded(s, need_vir, MDX_F_NONBONDED | (s->have_pme ? MDX_F_EXCL : 0)))) return rc;
         if ((rc = mdx_launch_pme(s, need_vir))) return rc;
+        if ((s->dbg & 1024) && !need_vir) if ((rc = mdx_launch_pme(s, need_vir))) return rc;         // timing experiment: the (idempotent) PME chain twice
         if ((rc = mdx_launch_bonded(s, need_vir, MDX_F_BONDED | MDX_F_POSRES))) return rc;
         if (s->pull_on) {
             const bool log_now = (step % s->pull_nstout == 0);
@@ -698,6 +716,21 @@ extern "C" int mdx_step(mdx_system *s, long long nsteps)
         }
         if ((rc = mdx_join(s))) return rc;
         if ((rc = mdx_launch_update(s, tc_apply, s->pcoupl == 2, need_vir))) return rc;
+        // The PME and bonded kernels of the next step read only the new positions (the spread goes through the
+        // sort permutation): when that step neither rebuilds the list nor accumulates energies they are
+        // released here, ahead of the thermostat kernels and the coordinate sort, instead of by the prepare kernel.
+        forked_early = false;
+        {
+            const long long nx = step + 1;
+            const bool vir_next = (s->nstcalcenergy > 0 && nx % s->nstcalcenergy == 0) || (s->pcoupl != 0 && nx % s->nstpcouple == 0);
+            const bool search_next = s->steps_since_search + 1 >= s->nstlist;
+            if (it + 1 < nsteps && !vir_next && !search_next && !do_pc && s->early_fork) {
+                MDX_CHECK(s, hipEventRecord(s->ev_fork, s->stream));
+                MDX_CHECK(s, hipStreamWaitEvent(s->st_pme, s->ev_fork, 0));
+                MDX_CHECK(s, hipStreamWaitEvent(s->st_bond, s->ev_fork, 0));
+                forked_early = true;
+            }
+        }
         if (need_vir) {
             if ((rc = mdx_launch_ke(s, false, true))) return rc;
             if ((rc = mdx_launch_finish_energy(s))) return rc;

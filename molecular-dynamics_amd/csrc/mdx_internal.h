@@ -12,6 +12,7 @@
 #define MDX_MAX_SHIFTS 48
 #define MDX_NB_CHUNK 32          // j-clusters per nonbonded work unit
 #define MDX_MAX_COL 2048         // atoms per grid column handled by the in-LDS sort
+#define MDX_GTAB_N 4096          // points of the tabulated Ewald correction used by the force-only nonbonded kernel
 #define MDX_LINCS_MAXK 16        // constraints per coupled component
 
 // Device-resident scalars: written by kernels, read by kernels, copied to the host on demand.
@@ -51,7 +52,7 @@ struct DevState {
     unsigned long long ntiles;    // 8x8 tiles in the pair list (statistics)
     int cost_hist[258];           // work units per tile count (last bin: 256 and more), filled by the list builder
     int cost_cursor[258];         // positions handed out per tile count by the sort of the units
-    int work_head[8];             // per-queue dequeue counters of the nonbonded kernel (cleared every step)
+    int nb_head[8 * 32];          // dequeue counters of the nonbonded kernel's eight unit queues, one cache line each (cleared every step)
     // Replicated accumulators of the energy steps: thousands of workgroups adding doubles to one
     // address serialise in L2, so each adds to replica (block index mod MDX_NREP) and
     // k_finish_energy folds the replicas into ener / vir / ekin_tensor / npairs.
@@ -85,6 +86,11 @@ struct mdx_system {
     long long pull_log_popped = 0;
     bool pull_reset_pending = false;
     int dbg = 0;                       // diagnostic ablation bits (mdx_debug_set key 2)
+    int nb_dyn = 1;                    // nonbonded kernel: rounds' worth of cheap units scheduled dynamically (mdx_debug_set key 3)
+    int nb_dyn_split = 0;              // ... in 2^nb_dyn_split parts per unit (mdx_debug_set key 4)
+    int bond_on_main = 0;              // bonded and pull kernels behind the nonbonded kernel on the main stream (mdx_debug_set key 6)
+    int early_fork = 1;                // release the side streams of a plain step right after the previous update (mdx_debug_set key 5)
+    long long *nb_wave_t = nullptr;    // diagnostic per-wave clock buffer (mdx_debug_wave_times)
     int nb_variant = 33;               // nonbonded launch shape: 10 * waves/SIMD of the energy kernel + waves/SIMD of the force kernel
     hipStream_t stream = nullptr;      // main stream: search, nonbonded, update
     hipStream_t st_pme = nullptr;      // PME chain (spread, FFTs, solve, gather) overlaps the nonbonded kernel
@@ -134,12 +140,15 @@ struct mdx_system {
     std::vector<int3> h_shift_ijk;
     // nonbonded parameters
     float rc = 1.0f, rlist = 1.1f, beta = 3.12341f;
+    float2 *gtab = nullptr;       // MDX_GTAB_N entries of the Ewald correction g on a uniform r^2 grid up to rc^2
     int nstlist = 10;
     // PME
     int K[3] = {0, 0, 0};
     float *grid = nullptr; float2 *cgrid = nullptr;
     float *bmod[3] = {nullptr, nullptr, nullptr};
     hipfftHandle plan_r2c = 0, plan_c2r = 0;
+    float2 *fftW[3] = {nullptr, nullptr, nullptr};   // twiddle tables exp(-2 pi i j / K) of the own transform
+    bool own_fft = false;         // every grid dimension splits into two factors <= 32: the own transform is used
     bool have_pme = false;
     // bonded
     int nbonds = 0; int2 *bond_ij = nullptr; float2 *bond_p = nullptr;

@@ -11,6 +11,7 @@
 // Pair arithmetic: F/r = [4 eps (12 s6^2 - 6 s6) + qq (erfc(br) + 2/sqrt(pi) br exp(-b^2 r^2)) / r] / r^2
 // with Lorentz-Berthelot sigma/eps from per-atom (sigma/2, 2 sqrt(eps)) so no type table gather.
 #include "mdx_internal.h"
+#include <hip/hip_ext.h>
 #include <cstdlib>
 #include <type_traits>
 #include <cstddef>
@@ -31,6 +32,11 @@ struct NbArgs {
     int central;                 // index of the zero lattice shift
     int do_pairs, do_excl;       // evaluate listed pairs / the Ewald correction of excluded pairs
     int dbg;                     // diagnostic ablation bits (timing experiments only)
+    const float2 *gtab;          // MDX_GTAB_N entries (g(w_k), g(w_k+1) - g(w_k)), w_k = beta^2 rc^2 k / MDX_GTAB_N
+    float tab_scale;             // MDX_GTAB_N / rc^2
+    int dyn_split;               // log2 of the parts a unit is cut into when handed out dynamically
+    int dyn;                     // rounds' worth of units at the cheap end of the list handed out dynamically (0: static deal only)
+    long long *wave_t;           // diagnostic: per wave (start clock, end clock, wall start, wall end, units, entries)
 };
 
 // Cross-lane adds inside groups of 8 consecutive lanes as DPP moves (no LDS crossbar traffic).
@@ -70,13 +76,17 @@ __device__ __forceinline__ float mdx_pmecorr(float w)
 // load and broadcast with v_readlane, the j-atoms of entry e+1 are requested before entry e is
 // evaluated, two j-clusters share one 48-lane float atomic, and the force-only variant replaces
 // exp + erfc by the rational Ewald correction above.
-template <bool ENERGY>
-__device__ __forceinline__ void nb_body(const NbArgs &A)
+// ABL bits: 1, 2 remove arithmetic (timing experiments); 4 takes the Ewald correction g from the table `gtab` in LDS.
+template <bool ENERGY, bool TIMED = false, int ABL = 0>
+__device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nullptr)
 {
+    long long t_start = 0, w_start = 0; int n_units = 0, n_entries = 0;
+    if (TIMED) { t_start = clock64(); w_start = wall_clock64(); }
     const int lane = threadIdx.x & 63;
     const int ti = lane & 7, tj = lane >> 3;
     const int nwork = A.d->nwork;
-    const int nwaves = gridDim.x * 4;
+    const int wpb = blockDim.x >> 6;          // waves per workgroup
+    const int nwaves = gridDim.x * wpb;
     float elj = 0.0f, ecoul = 0.0f, eexcl = 0.0f;
     unsigned int npair = 0, nlj = 0;
     const bool do_pairs = A.do_pairs != 0, do_excl = A.do_excl != 0;
@@ -84,18 +94,49 @@ __device__ __forceinline__ void nb_body(const NbArgs &A)
     const float rc2 = A.rc2, beta = A.beta;
     const float beta2 = beta * beta, beta3 = beta2 * beta;
     const float nb2l2e = -beta2 * 1.4426950408889634f;
-    // Work units are sorted by descending cost; a static snake deal over the sorted order keeps the
-    // waves balanced (a returning-atomic work queue measured 1.6x slower than this).
-    const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
-    for (int round = 0; round * nwaves < nwork; round++) {
-        // snake order over the cost-sorted units: even rounds ascend, odd rounds descend
-        const int unit = (round & 1) ? (round + 1) * nwaves - 1 - wave_id : round * nwaves + wave_id;
-        if (unit >= nwork) continue;
-        const NbWork w = A.work[A.order[unit]];
+    // Work units are sorted by descending cost. The expensive ones are dealt statically in snake order
+    // over the sorted list (balanced per wave, no queue traffic). A SIMD issues for its oldest wave first,
+    // so its waves finish far apart and a purely static deal leaves the SIMD to one or two waves for
+    // the last third of the launch: the cheap end of the list is therefore handed out dynamically, from
+    // eight interleaved queues (wave index mod 8; heads on separate cache lines), and the ticket for the
+    // next unit is requested before the loads of the current one so that its latency is covered.
+    const int wave_id = blockIdx.x * wpb + (threadIdx.x >> 6);
+    const int q = wave_id & 7;
+    const int nstatic = A.dyn > 0 ? max(1, nwork / nwaves - A.dyn) : (nwork + nwaves - 1) / nwaves;
+    // snake order over the cost-sorted units: even rounds ascend, odd rounds descend
+    auto static_unit = [&](int r) { return (r & 1) ? (r + 1) * nwaves - 1 - wave_id : r * nwaves + wave_id; };
+    const int split = A.dyn_split, pmask = (1 << split) - 1;
+    const int dyn_base = nstatic * nwaves + q;
+    int *head = &A.dw->nb_head[q * 32];
+    // Two-deep pipeline over the units of this wave: the ticket of the unit after the next and the
+    // header of the next unit are requested before the current unit is evaluated, so a new unit starts
+    // with its header in registers (a unit index >= nwork means "none").
+    int unit = static_unit(0), part = 0, unit_n = nwork, part_n = 0;
+    if (1 < nstatic) unit_n = static_unit(1);
+    else if (A.dyn > 0) {
+        int t0 = 0;
+        if (lane == 0) t0 = atomicAdd(head, 1);
+        t0 = __builtin_amdgcn_readfirstlane(t0);
+        unit_n = dyn_base + 8 * (t0 >> split); part_n = t0 & pmask;
+    }
+    NbWork w; w.sci = 0; w.shift = 0; w.cj_start = 0; w.cj_end = 0;
+    if (unit < nwork) w = A.work[A.order[unit]];
+    for (int slot = 0; unit < nwork; slot++) {
+        int tk = 0;
+        if (A.dyn > 0 && slot + 2 >= nstatic && lane == 0) tk = atomicAdd(head, 1);
+        NbWork w_n = w;
+        if (unit_n < nwork) w_n = A.work[A.order[unit_n]];
         const int sci = __builtin_amdgcn_readfirstlane(w.sci);
-        const int e0 = __builtin_amdgcn_readfirstlane(w.cj_start);
-        const int count = __builtin_amdgcn_readfirstlane(w.cj_end) - e0;
+        int e0 = __builtin_amdgcn_readfirstlane(w.cj_start);
+        int count = __builtin_amdgcn_readfirstlane(w.cj_end) - e0;
+        if (slot >= nstatic) {
+            // a dynamic ticket is one of 2^split equal parts of a unit: the finer the grain, the closer the waves finish
+            const int c0 = (count * part) >> split, c1 = (count * (part + 1)) >> split;
+            e0 += c0; count = c1 - c0;
+        }
+        if (count > 0) {
         const int shift_idx = __builtin_amdgcn_readfirstlane(w.shift) & 0xFF;
+        if (TIMED) { n_units++; n_entries += count; }
         const bool is_central = shift_idx == A.central;
         const float4 S = A.shiftvec[shift_idx];
         NbEntry myent; myent.cj = 0; myent.mask = 0;
@@ -187,7 +228,15 @@ __device__ __forceinline__ void nb_body(const NbArgs &A)
                     // (t6 (12 s6 - 6) + qq/r) / r^2 - qq beta^3 g; an excluded pair keeps only the last term
                     fs = fmaf(qq, rinv, fs) * rinv2;
                     if (GENERAL && slot) fs = listed ? fs : 0.0f;      // wave-uniform: few tiles hold an excluded pair
-                    fs = fmaf(-qq * beta3, mdx_pmecorr(beta2 * r2), fs);
+                    float g;
+                    if (ABL & 4) {
+                        // g(beta^2 r^2) by linear interpolation in a table uniform in r^2 (entry: value, step to the next):
+                        // the look-up runs on the LDS pipe next to the LJ arithmetic and replaces a dozen VALU instructions
+                        const float t = r2 * A.tab_scale;
+                        const float2 te = gtab[(unsigned)t & (MDX_GTAB_N - 1)];
+                        g = fmaf(__builtin_amdgcn_fractf(t), te.y, te.x);
+                    } else g = (ABL & 1) ? beta2 * r2 : mdx_pmecorr(beta2 * r2);
+                    fs = fmaf(-qq * beta3, g, fs);
                 }
                 fs = within ? fs : 0.0f;
                 const float fx = fs * dx, fy = fs * dy, fz = fs * dz;
@@ -219,7 +268,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A)
                     if (imask & (1u << c)) tile(std::true_type{}, c);
             }
             // an entry none of whose tiles had a pair inside the cutoff has no j-force to reduce or add
-            if (did) { fjx = sum8(fjx); fjy = sum8(fjy); fjz = sum8(fjz); }
+            if (did && !(ABL & 2)) { fjx = sum8(fjx); fjy = sum8(fjy); fjz = sum8(fjz); }
             const int ja3 = 3 * (cj * 8 + tj);
             if (((e & 1) == 0) && (e + 1 < count)) {
                 // keep this cluster's components on lanes ti = 0..2 until the next one is ready
@@ -249,6 +298,18 @@ __device__ __forceinline__ void nb_body(const NbArgs &A)
                 atomicAdd(&A.f_s[3 * ((sci * 8 + c) * 8 + ti) + tj], val);
             }
         }
+        }
+        unit = unit_n; part = part_n; w = w_n;
+        if (slot + 2 < nstatic) { unit_n = static_unit(slot + 2); part_n = 0; }
+        else if (A.dyn > 0) {
+            const int t = __builtin_amdgcn_readfirstlane(tk);
+            unit_n = dyn_base + 8 * (t >> split); part_n = t & pmask;
+        } else unit_n = nwork;
+    }
+    if (TIMED && (threadIdx.x & 63) == 0) {
+        long long *o = A.wave_t + 8 * (size_t)wave_id;
+        o[0] = t_start; o[1] = clock64(); o[2] = w_start; o[3] = wall_clock64(); o[4] = n_units; o[5] = n_entries;
+        o[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4); o[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_ID, XCC_ID
     }
     if (ENERGY) {
         elj = wave_sum(elj); ecoul = wave_sum(ecoul); eexcl = wave_sum(eexcl);
@@ -280,6 +341,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // Variant that leaves a quarter of each SIMD's wave slots and registers to the kernels of the
 // PME and bonded streams (selected with mdx_debug_set key 1 = 3).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3(NbArgs A) { nb_body<false>(A); }
+// Force-only kernel with the Ewald correction tabulated in LDS. One workgroup of 12 waves per CU (3 waves per
+// SIMD) so that a CU holds the 32 KB table once and the LDS left over serves the co-running PME kernels.
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3t(NbArgs A)
+{
+    __shared__ float4 tab4[MDX_GTAB_N / 2];
+    const float4 *src = (const float4 *)A.gtab;
+    for (int k = threadIdx.x; k < MDX_GTAB_N / 2; k += 768) tab4[k] = src[k];
+    __syncthreads();
+    nb_body<false, false, 4>(A, (const float2 *)tab4);
+}
+// The same at 128 registers (a few spills): leaves half a SIMD's register file to co-running kernels.
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_f3t128(NbArgs A)
+{
+    __shared__ float4 tab4[MDX_GTAB_N / 2];
+    const float4 *src = (const float4 *)A.gtab;
+    for (int k = threadIdx.x; k < MDX_GTAB_N / 2; k += 768) tab4[k] = src[k];
+    __syncthreads();
+    nb_body<false, false, 4>(A, (const float2 *)tab4);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3_abl1(NbArgs A) { nb_body<false, false, 1>(A); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3_abl2(NbArgs A) { nb_body<false, false, 2>(A); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3_timed(NbArgs A) { nb_body<false, true>(A); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_nonbonded_f2(NbArgs A) { nb_body<false>(A); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_nonbonded_ev2(NbArgs A) { nb_body<true>(A); }
 
@@ -288,6 +371,9 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
     NbArgs A;
     A.central = s->central_shift;
     A.dbg = s->dbg;
+    A.wave_t = s->nb_wave_t;
+    A.dyn = s->nb_dyn; A.dyn_split = s->nb_dyn_split;
+    A.gtab = s->gtab; A.tab_scale = (float)MDX_GTAB_N / (s->rc * s->rc);
     A.do_pairs = (terms & MDX_F_NONBONDED) ? 1 : 0;
     A.do_excl = ((terms & MDX_F_EXCL) && s->beta > 0.0f) ? 1 : 0;
     if (!A.do_pairs && !A.do_excl) return MDX_OK;
@@ -302,26 +388,30 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
     int wv = energy ? s->nb_variant / 10 : s->nb_variant % 10;
     if (wv < 2 || wv > 4 || (energy && wv == 4)) wv = 3;
     const int nblk = 256 * wv;
-    // kernel timing brackets every 8th launch: two event records per step would themselves cost microseconds
-    int e0 = -1, e1 = -1;
-    const bool timed = s->time_nb && (s->nb_launch_seq++ % 8 == 0);
+    // kernel timing samples every 8th launch: the start and stop events ride on the kernel's own dispatch
+    // packet, so they read the kernel's begin and end time stamps (no marker packets, no launch gap inside)
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    // (force-only launches only, at a stride that does not lock onto the 10- and 20-step cadences of energy and search steps)
+    const bool timed = s->time_nb && (s->nb_launch_seq++ % 7 == 0) && !energy;
     if (timed) {
-        hipEvent_t a, b;
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { s->err = "hipEventCreate failed"; return MDX_ERR_HIP; }
-        s->ev_pool.push_back(a); s->ev_pool.push_back(b);
-        e0 = (int)s->ev_pool.size() - 2; e1 = e0 + 1;
-        MDX_CHECK(s, hipEventRecord(s->ev_pool[e0], s->stream));
+        if (hipEventCreate(&ev_a) != hipSuccess || hipEventCreate(&ev_b) != hipSuccess) { s->err = "hipEventCreate failed"; return MDX_ERR_HIP; }
+        s->ev_pool.push_back(ev_a); s->ev_pool.push_back(ev_b);
+        s->ev_nb.push_back(std::make_pair((int)s->ev_pool.size() - 2, (int)s->ev_pool.size() - 1));
     }
-    if (energy && wv == 2) hipLaunchKernelGGL(k_nonbonded_ev2, dim3(nblk), dim3(256), 0, s->stream, A);
-    else if (energy) hipLaunchKernelGGL(k_nonbonded_ev, dim3(nblk), dim3(256), 0, s->stream, A);
-    else if (wv == 2) hipLaunchKernelGGL(k_nonbonded_f2, dim3(nblk), dim3(256), 0, s->stream, A);
-    else if (wv == 3) hipLaunchKernelGGL(k_nonbonded_f3, dim3(nblk), dim3(256), 0, s->stream, A);
-    else hipLaunchKernelGGL(k_nonbonded_f, dim3(nblk), dim3(256), 0, s->stream, A);
+    void (*kern)(NbArgs) = k_nonbonded_f;
+    dim3 grid(nblk), block(256);
+    if (energy && wv == 2) kern = k_nonbonded_ev2;
+    else if (energy) kern = k_nonbonded_ev;
+    else if (wv == 2) kern = k_nonbonded_f2;
+    else if (wv == 3) {
+        if (s->nb_wave_t) kern = k_nonbonded_f3_timed;
+        else if (s->dbg & 0x100000) kern = k_nonbonded_f3_abl1;
+        else if (s->dbg & 0x200000) kern = k_nonbonded_f3_abl2;
+        else if ((s->dbg & 0x400000) || !s->gtab) kern = k_nonbonded_f3;
+        else { kern = (s->dbg & 0x800000) ? k_nonbonded_f3t128 : k_nonbonded_f3t; grid = dim3(256); block = dim3(768); }
+    }
+    hipExtLaunchKernelGGL(kern, grid, block, 0, s->stream, ev_a, ev_b, 0, A);
     MDX_CHECK(s, hipGetLastError());
-    if (timed) {
-        MDX_CHECK(s, hipEventRecord(s->ev_pool[e1], s->stream));
-        s->ev_nb.push_back(std::make_pair(e0, e1));
-    }
     return MDX_OK;
 }
 
@@ -333,11 +423,11 @@ extern "C" int mdx_debug_time_nonbonded(mdx_system *s, int energy, int iters, do
     hipEvent_t a, b;
     MDX_CHECK(s, hipEventCreate(&a)); MDX_CHECK(s, hipEventCreate(&b));
     const bool keep = s->time_nb; s->time_nb = false;
-    (void)hipMemsetAsync((char *)s->d + offsetof(DevState, work_head), 0, sizeof(int) * 8, s->stream);
+    (void)hipMemsetAsync((char *)s->d + offsetof(DevState, nb_head), 0, sizeof(int) * 8 * 32, s->stream);
     int rc = mdx_launch_nonbonded(s, energy != 0, MDX_F_NONBONDED | MDX_F_EXCL);          // warm
     MDX_CHECK(s, hipEventRecord(a, s->stream));
     for (int i = 0; i < iters && rc == MDX_OK; i++) {
-        (void)hipMemsetAsync((char *)s->d + offsetof(DevState, work_head), 0, sizeof(int) * 8, s->stream);
+        (void)hipMemsetAsync((char *)s->d + offsetof(DevState, nb_head), 0, sizeof(int) * 8 * 32, s->stream);
         rc = mdx_launch_nonbonded(s, energy != 0, MDX_F_NONBONDED | MDX_F_EXCL);
     }
     MDX_CHECK(s, hipEventRecord(b, s->stream));
@@ -350,9 +440,35 @@ extern "C" int mdx_debug_time_nonbonded(mdx_system *s, int energy, int iters, do
     return rc;
 }
 
+// Diagnostic: one launch of the force-only kernel (3 waves/SIMD shape) with per-wave clocks; out holds 8 values per wave
+// (shader clock at start and end, 100 MHz wall clock at start and end, work units, list entries, HW_ID, XCC_ID).
+extern "C" int mdx_debug_wave_times(mdx_system *s, long long *out, int max_waves, int *nwaves)
+{
+    (void)hipSetDevice(s->device);
+    const int nw = 256 * 3 * 4;
+    if (!out || max_waves < nw) { s->err = "mdx_debug_wave_times: buffer too small"; return MDX_ERR_ARG; }
+    long long *d = nullptr;
+    MDX_CHECK(s, hipMalloc((void **)&d, sizeof(long long) * 8 * nw));
+    MDX_CHECK(s, hipMemsetAsync(d, 0, sizeof(long long) * 8 * nw, s->stream));
+    const int keep_var = s->nb_variant; const bool keep = s->time_nb;
+    s->nb_variant = 33; s->time_nb = false; s->nb_wave_t = d;
+    (void)hipMemsetAsync((char *)s->d + offsetof(DevState, nb_head), 0, sizeof(int) * 8 * 32, s->stream);
+    int rc = mdx_launch_nonbonded(s, false, MDX_F_NONBONDED | MDX_F_EXCL);
+    s->nb_wave_t = nullptr; s->nb_variant = keep_var; s->time_nb = keep;
+    if (rc == MDX_OK && hipMemcpyAsync(out, d, sizeof(long long) * 8 * nw, hipMemcpyDeviceToHost, s->stream) != hipSuccess) rc = MDX_ERR_HIP;
+    if (hipStreamSynchronize(s->stream) != hipSuccess) rc = MDX_ERR_HIP;
+    (void)hipFree(d);
+    if (nwaves) *nwaves = nw;
+    return rc;
+}
+
 extern "C" int mdx_debug_set(mdx_system *s, int key, int value)
 {
     if (key == 1) { s->nb_variant = value; return MDX_OK; }
     if (key == 2) { s->dbg = value; return MDX_OK; }
+    if (key == 3) { s->nb_dyn = value; return MDX_OK; }
+    if (key == 6) { s->bond_on_main = value; return MDX_OK; }
+    if (key == 5) { s->early_fork = value; return MDX_OK; }
+    if (key == 4 && value >= 0 && value <= 3) { s->nb_dyn_split = value; return MDX_OK; }
     s->err = "mdx_debug_set: unknown key"; return MDX_ERR_ARG;
 }

@@ -520,7 +520,7 @@ __global__ void k_prepare(int npad, DevState *__restrict__ d, const float4 *__re
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const float *h = d->box.h;
-    if (g < 8) d->work_head[g] = 0;          // work queues of the nonbonded kernel
+    if (g < 8) d->nb_head[g * 32] = 0;       // unit queues of the nonbonded kernel
     if (g < nshift) {
         const int3 s = shift_ijk[g];
         shiftvec[g] = make_float4(s.x * h[0] + s.y * h[3] + s.z * h[6], s.y * h[4] + s.z * h[7], s.z * h[8], 0.0f);

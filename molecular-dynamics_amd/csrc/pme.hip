@@ -211,6 +211,182 @@ __global__ __launch_bounds__(256) void k_pme_solve(float2 *__restrict__ cgrid, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Own 3D transform for PME-sized grids (a few MB): five launches of small workgroups that fit into
+// the registers and LDS the nonbonded kernel leaves free, where the library's 3D plan uses 400-thread
+// workgroups that wait for a CU to drain. A line of length N = N1 N2 is transformed in LDS by two
+// direct DFT passes (Cooley-Tukey split, N1 + N2 complex multiply-adds per point: at N <= 160 the
+// arithmetic is negligible against the launch). Passes: x (real to half-complex), y, z forward +
+// influence function + z inverse in one kernel, y inverse, x inverse (half-complex to real).
+// Unnormalised in both directions, layout of cgrid (K2, K1, K0/2+1) as hipFFT's R2C plan.
+struct FftArgs {
+    const float *grid_in; float *grid_out; float2 *cgrid;
+    const float2 *W;            // exp(-2 pi i j / N), j < N, of the transformed dimension
+    int K0, K1, K2, K0c;
+    int N, N1, N2;
+    int nl;                     // lines per workgroup
+    // influence function (z pass)
+    const DevState *d; DevState *dw; const float *bm0, *bm1, *bm2; float beta;
+};
+
+// nl lines of length N at a[l * (N + 1)]; result in a again (b is scratch of the same size)
+__device__ __forceinline__ void dft_lines(float2 *a, float2 *b, const float2 *W, int nl, int N, int N1, int N2, bool inverse)
+{
+    const int stride = N + 1;
+    const float sgn = inverse ? -1.0f : 1.0f;
+    // pass 1: b[k1 N2 + n2] = W_N^(n2 k1) sum_n1 a[N2 n1 + n2] W_N^(N2 n1 k1)
+    for (int idx = threadIdx.x; idx < nl * N; idx += blockDim.x) {
+        const int line = idx / N, r = idx - line * N;
+        const int k1 = r / N2, n2 = r - k1 * N2;
+        const float2 *x = a + line * stride + n2;
+        float re = 0.0f, im = 0.0f;
+        int j = 0; const int step = k1 * N2;
+        for (int n1 = 0; n1 < N1; n1++) {
+            const float2 w = W[j]; const float2 v = x[n1 * N2];
+            const float wy = sgn * w.y;
+            re = fmaf(v.x, w.x, fmaf(-v.y, wy, re));
+            im = fmaf(v.x, wy, fmaf(v.y, w.x, im));
+            j += step; if (j >= N) j -= N;
+        }
+        const float2 t = W[n2 * k1]; const float ty = sgn * t.y;
+        b[line * stride + r] = make_float2(re * t.x - im * ty, re * ty + im * t.x);
+    }
+    __syncthreads();
+    // pass 2: a[k1 + N1 k2] = sum_n2 b[k1 N2 + n2] W_N^(N1 n2 k2)
+    for (int idx = threadIdx.x; idx < nl * N; idx += blockDim.x) {
+        const int line = idx / N, r = idx - line * N;
+        const int k1 = r / N2, k2 = r - k1 * N2;
+        const float2 *x = b + line * stride + k1 * N2;
+        float re = 0.0f, im = 0.0f;
+        int j = 0; const int step = k2 * N1;
+        for (int n2 = 0; n2 < N2; n2++) {
+            const float2 w = W[j]; const float2 v = x[n2];
+            const float wy = sgn * w.y;
+            re = fmaf(v.x, w.x, fmaf(-v.y, wy, re));
+            im = fmaf(v.x, wy, fmaf(v.y, w.x, im));
+            j += step; if (j >= N) j -= N;
+        }
+        a[line * stride + k1 + N1 * k2] = make_float2(re, im);
+    }
+    __syncthreads();
+}
+
+// MODE 0: x forward (real lines -> half-complex), 4: x inverse; 1 / 3: y forward / inverse; 2: z forward, solve, z inverse
+template <int MODE, bool ENERGY>
+__global__ __launch_bounds__(256) void k_pme_fft(FftArgs A)
+{
+    extern __shared__ float2 fsm[];
+    const int N = A.N, stride = N + 1, nl = A.nl;
+    float2 *Wl = fsm, *a = fsm + N, *b = a + nl * stride;
+    for (int j = threadIdx.x; j < N; j += blockDim.x) Wl[j] = A.W[j];
+    const int K0c = A.K0c;
+    if (MODE == 0 || MODE == 4) {
+        const int nlines = A.K1 * A.K2, L0 = blockIdx.x * nl;
+        if (MODE == 0) {
+            for (int idx = threadIdx.x; idx < nl * N; idx += blockDim.x) {
+                const int l = idx / N, n = idx - l * N;
+                a[l * stride + n] = make_float2(L0 + l < nlines ? A.grid_in[(size_t)(L0 + l) * N + n] : 0.0f, 0.0f);
+            }
+        } else {
+            for (int idx = threadIdx.x; idx < nl * K0c; idx += blockDim.x) {
+                const int l = idx / K0c, k = idx - l * K0c;
+                float2 v = make_float2(0.0f, 0.0f);
+                if (L0 + l < nlines) v = A.cgrid[(size_t)(L0 + l) * K0c + k];
+                a[l * stride + k] = v;
+                if (k > 0 && N - k >= K0c) a[l * stride + N - k] = make_float2(v.x, -v.y);
+            }
+        }
+        __syncthreads();
+        dft_lines(a, b, Wl, nl, N, A.N1, A.N2, MODE == 4);
+        if (MODE == 0) {
+            for (int idx = threadIdx.x; idx < nl * K0c; idx += blockDim.x) {
+                const int l = idx / K0c, k = idx - l * K0c;
+                if (L0 + l < nlines) A.cgrid[(size_t)(L0 + l) * K0c + k] = a[l * stride + k];
+            }
+        } else {
+            for (int idx = threadIdx.x; idx < nl * N; idx += blockDim.x) {
+                const int l = idx / N, n = idx - l * N;
+                if (L0 + l < nlines) A.grid_out[(size_t)(L0 + l) * N + n] = a[l * stride + n].x;
+            }
+        }
+        return;
+    }
+    // y and z passes: workgroup = (fixed other index, chunk of nl consecutive kx), lines run along the transformed dimension
+    const int nchunk = (K0c + nl - 1) / nl;
+    const int other = blockIdx.x / nchunk, kx0 = (blockIdx.x - other * nchunk) * nl;
+    const size_t base = (MODE == 2) ? (size_t)other * K0c : (size_t)other * A.K1 * K0c;       // z pass: other = y; y pass: other = z
+    const size_t estride = (MODE == 2) ? (size_t)A.K1 * K0c : (size_t)K0c;
+    for (int idx = threadIdx.x; idx < nl * N; idx += blockDim.x) {
+        const int n = idx / nl, c = idx - n * nl;
+        a[c * stride + n] = (kx0 + c < K0c) ? A.cgrid[base + (size_t)n * estride + kx0 + c] : make_float2(0.0f, 0.0f);
+    }
+    __syncthreads();
+    dft_lines(a, b, Wl, nl, N, A.N1, A.N2, MODE == 3);
+    if (MODE == 2) {
+        // influence function on (kx0 + c, y = other, kz = n); energy and virial as in the stand-alone solve kernel
+        double e = 0.0, v[6] = { 0, 0, 0, 0, 0, 0 };
+        const float *iv = A.d->box.inv;
+        const float pi = 3.14159265358979f;
+        const float fac = pi * pi / (A.beta * A.beta);
+        const float pivol = pi * A.d->box.vol;
+        const int K0 = A.K0, K1 = A.K1, K2 = A.K2;
+        for (int idx = threadIdx.x; idx < nl * N; idx += blockDim.x) {
+            const int k2 = idx / nl, c = idx - k2 * nl;
+            const int k0 = kx0 + c, k1 = other;
+            if (k0 >= K0c) continue;
+            const int m0 = k0;
+            const int m1 = (k1 < (K1 + 1) / 2) ? k1 : k1 - K1;
+            const int m2 = (k2 < (K2 + 1) / 2) ? k2 : k2 - K2;
+            float2 cv = a[c * stride + k2];
+            if (m0 != 0 || m1 != 0 || m2 != 0) {
+                const float mx = iv[0] * m0 + iv[1] * m1 + iv[2] * m2;
+                const float my = iv[3] * m0 + iv[4] * m1 + iv[5] * m2;
+                const float mz = iv[6] * m0 + iv[7] * m1 + iv[8] * m2;
+                const float msq = mx * mx + my * my + mz * mz;
+                const float denom = msq * A.bm0[k0] * A.bm1[k1] * A.bm2[k2] * pivol;
+                const float eterm = MDX_ONE_4PI_EPS0 * __expf(-fac * msq) / denom;
+                if (ENERGY) {
+                    const float mult = (k0 == 0 || (K0 % 2 == 0 && k0 == K0 / 2)) ? 1.0f : 2.0f;
+                    const double em = 0.5 * mult * (double)eterm * ((double)cv.x * cv.x + (double)cv.y * cv.y);
+                    e += em;
+                    const double vf = 2.0 * (1.0 + fac * msq) / msq;
+                    v[0] += em * (1.0 - vf * mx * mx); v[1] += em * (-vf * mx * my); v[2] += em * (-vf * mx * mz);
+                    v[3] += em * (1.0 - vf * my * my); v[4] += em * (-vf * my * mz); v[5] += em * (1.0 - vf * mz * mz);
+                }
+                cv.x *= eterm; cv.y *= eterm;
+            } else cv = make_float2(0.0f, 0.0f);
+            a[c * stride + k2] = cv;
+        }
+        if (ENERGY) {
+            __shared__ double red[16];
+            double r = block_sum_d(e, red);
+            if (threadIdx.x == 0) atomicAdd(&MDX_ENER(A.dw, MDX_E_COUL_RECIP), r);
+            const int map[6][2] = { { 0, 0 }, { 1, 3 }, { 2, 6 }, { 4, 4 }, { 5, 7 }, { 8, 8 } };
+            for (int k = 0; k < 6; k++) {
+                r = block_sum_d(v[k], red);
+                if (threadIdx.x == 0) {
+                    atomicAdd(&MDX_VIR(A.dw, map[k][0]), -0.5 * r);
+                    if (map[k][1] != map[k][0]) atomicAdd(&MDX_VIR(A.dw, map[k][1]), -0.5 * r);
+                }
+            }
+        }
+        __syncthreads();
+        dft_lines(a, b, Wl, nl, N, A.N1, A.N2, true);
+    }
+    for (int idx = threadIdx.x; idx < nl * N; idx += blockDim.x) {
+        const int n = idx / nl, c = idx - n * nl;
+        if (kx0 + c < K0c) A.cgrid[base + (size_t)n * estride + kx0 + c] = a[c * stride + n];
+    }
+}
+
+// N = N1 N2 with the smallest N1 + N2; false when a factor would exceed 32 (the library plan serves those grids)
+static bool fft_split(int N, int &N1, int &N2)
+{
+    N1 = 1; N2 = N;
+    for (int a = 1; a * a <= N; a++) if (N % a == 0) { N1 = a; N2 = N / a; }
+    return N2 <= 32 && N <= 512;
+}
+
 // 16 lanes per atom gather phi and spline derivatives; reduced with shuffles, one lane adds the force.
 __global__ __launch_bounds__(256) void k_pme_gather(int n, const float4 *__restrict__ x, const DevState *__restrict__ d,
                                                     int K0, int K1, int K2, const float *__restrict__ phi, float *__restrict__ f)
@@ -292,6 +468,15 @@ int mdx_pme_init(mdx_system *s)
     }
     hipfftSetStream(s->plan_r2c, s->st_pme);
     hipfftSetStream(s->plan_c2r, s->st_pme);
+    s->own_fft = true;
+    for (int d = 0; d < 3; d++) {
+        int n1, n2;
+        if (!fft_split(s->K[d], n1, n2)) s->own_fft = false;
+        std::vector<float2> w(s->K[d]);
+        for (int j = 0; j < s->K[d]; j++) w[j] = make_float2((float)cos(2.0 * M_PI * j / s->K[d]), (float)-sin(2.0 * M_PI * j / s->K[d]));
+        MDX_CHECK(s, hipMalloc((void **)&s->fftW[d], sizeof(float2) * s->K[d]));
+        MDX_CHECK(s, hipMemcpy(s->fftW[d], w.data(), sizeof(float2) * s->K[d], hipMemcpyHostToDevice));
+    }
     s->have_pme = true;
     return MDX_OK;
 }
@@ -301,6 +486,7 @@ void mdx_pme_free(mdx_system *s)
     if (s->grid) { (void)hipFree(s->grid); s->grid = nullptr; }
     if (s->cgrid) { (void)hipFree(s->cgrid); s->cgrid = nullptr; }
     for (int d = 0; d < 3; d++) if (s->bmod[d]) { (void)hipFree(s->bmod[d]); s->bmod[d] = nullptr; }
+    for (int d = 0; d < 3; d++) if (s->fftW[d]) { (void)hipFree(s->fftW[d]); s->fftW[d] = nullptr; }
     if (s->plan_r2c) { hipfftDestroy(s->plan_r2c); s->plan_r2c = 0; }
     if (s->plan_c2r) { hipfftDestroy(s->plan_c2r); s->plan_c2r = 0; }
     s->have_pme = false;
@@ -336,6 +522,29 @@ int mdx_launch_pme(mdx_system *s, bool energy)
         hipLaunchKernelGGL(k_pme_spread_col, dim3(s->ncx * s->ncy, nchunk), dim3(256), lds, s->st_pme, A, s->d);
     }
     if (s->dbg & 256) { MDX_CHECK(s, hipGetLastError()); return MDX_OK; }       // diagnostic: spreading only
+    if (s->own_fft && !(s->dbg & 512)) {
+        FftArgs F;
+        F.grid_in = s->grid; F.grid_out = s->grid; F.cgrid = s->cgrid; F.K0 = K0; F.K1 = K1; F.K2 = K2; F.K0c = K0 / 2 + 1;
+        F.d = s->d; F.dw = s->d; F.bm0 = s->bmod[0]; F.bm1 = s->bmod[1]; F.bm2 = s->bmod[2]; F.beta = s->beta;
+        auto lds = [](const FftArgs &f) { return sizeof(float2) * ((size_t)f.N + 2 * (size_t)f.nl * (f.N + 1)); };
+        const int nchunk = (F.K0c + 7) / 8;
+        // x forward
+        F.N = K0; fft_split(K0, F.N1, F.N2); F.W = s->fftW[0]; F.nl = 16;
+        hipLaunchKernelGGL((k_pme_fft<0, false>), dim3((K1 * K2 + F.nl - 1) / F.nl), dim3(256), lds(F), s->st_pme, F);
+        // y forward
+        F.N = K1; fft_split(K1, F.N1, F.N2); F.W = s->fftW[1]; F.nl = 8;
+        hipLaunchKernelGGL((k_pme_fft<1, false>), dim3(K2 * nchunk), dim3(256), lds(F), s->st_pme, F);
+        // z forward, influence function, z inverse
+        F.N = K2; fft_split(K2, F.N1, F.N2); F.W = s->fftW[2]; F.nl = 8;
+        if (energy) hipLaunchKernelGGL((k_pme_fft<2, true>), dim3(K1 * nchunk), dim3(256), lds(F), s->st_pme, F);
+        else hipLaunchKernelGGL((k_pme_fft<2, false>), dim3(K1 * nchunk), dim3(256), lds(F), s->st_pme, F);
+        // y inverse
+        F.N = K1; fft_split(K1, F.N1, F.N2); F.W = s->fftW[1]; F.nl = 8;
+        hipLaunchKernelGGL((k_pme_fft<3, false>), dim3(K2 * nchunk), dim3(256), lds(F), s->st_pme, F);
+        // x inverse
+        F.N = K0; fft_split(K0, F.N1, F.N2); F.W = s->fftW[0]; F.nl = 16;
+        hipLaunchKernelGGL((k_pme_fft<4, false>), dim3((K1 * K2 + F.nl - 1) / F.nl), dim3(256), lds(F), s->st_pme, F);
+    } else {
     if (hipfftExecR2C(s->plan_r2c, s->grid, (hipfftComplex *)s->cgrid) != HIPFFT_SUCCESS) { s->err = "hipfftExecR2C failed"; return MDX_ERR_HIP; }
     const int nbs = (int)((ncx + 255) / 256);
     if (energy)
@@ -343,6 +552,7 @@ int mdx_launch_pme(mdx_system *s, bool energy)
     else
         hipLaunchKernelGGL(k_pme_solve<false>, dim3(nbs), dim3(256), 0, s->st_pme, s->cgrid, s->d, s->d, K0, K1, K2, s->bmod[0], s->bmod[1], s->bmod[2], s->beta);
     if (hipfftExecC2R(s->plan_c2r, (hipfftComplex *)s->cgrid, s->grid) != HIPFFT_SUCCESS) { s->err = "hipfftExecC2R failed"; return MDX_ERR_HIP; }
+    }
     // the completion signal of the last kernel of the chain is the event the main stream waits for
     hipExtLaunchKernelGGL(k_pme_gather, dim3(nb), dim3(256), 0, s->st_pme, nullptr, s->ev_pme, 0, s->n, (const float4 *)s->x,
                           (const DevState *)s->d, K0, K1, K2, (const float *)s->grid, s->f_pme);

@@ -1,0 +1,11 @@
+#!/bin/bash
+# A/B of bench.py arguments on one box: bash tools/ab_args.sh "label=ARGS" ...
+for spec in "$@"; do
+  label=${spec%%=*}; args=${spec#*=}
+  timeout -k 10 200 python bench.py --no-cpu-baseline --steps 3000 --warmup 300 $args > gpurun_out/ab_$label.json 2> gpurun_out/ab_$label.err || { tail -3 gpurun_out/ab_$label.err; exit 1; }
+  python - "$label" <<'PY'
+import json, sys
+d = json.load(open("gpurun_out/ab_%s.json" % sys.argv[1]))
+print("%-28s %8.1f ns/day  %.4f ms/step  nb %.1f us" % (sys.argv[1], d["value"], d["ms_per_step"], d["roofline"]["avg_launch_ms"] * 1e3))
+PY
+done
