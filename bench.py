@@ -218,7 +218,7 @@ def main():
             "pair_interactions_per_s_end_to_end": round(n_rc * args.steps / elapsed_max * world, 1),
             "roofline": {"bound": "valu_f32", "kernel": "k_nonbonded", "achieved": round(achieved, 3), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (PMC, water box of the same size; profiles/r01/nb_pmc_traffic.json)",
+                         "traffic_unit": "HBM bytes per launch (separate rocprofv3 --pmc passes on this workload; profiles/r01/nb_pmc_traffic.json)",
                          "peak_unpacked": 78.6, "frac_unpacked": round(achieved / 78.6, 4),
                          "flops_per_launch": flops, "pairs_within_rc": n_rc, "pairs_with_lj": n_lj,
                          "avg_launch_ms": round(nb_avg_s * 1e3, 5), "launches": nb_launches,

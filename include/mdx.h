@@ -201,6 +201,8 @@ int mdx_debug_time_nonbonded(mdx_system *sys, int energy, int iters, double *avg
 int mdx_debug_set(mdx_system *sys, int key, int value);
 /* One launch of the force-only nonbonded kernel with per-wave clocks: 8 values per wave (shader clock
  * at start and end, 100 MHz wall clock at start and end, work units, list entries, HW_ID, XCC_ID). */
+/* Diagnostic build (-DMDX_STAMPS) only: reset, or read, the per-kernel first-start / last-end time stamps. */
+int mdx_debug_stamps(mdx_system *sys, int reset, long long *out48);
 int mdx_debug_wave_times(mdx_system *sys, long long *out, int max_waves, int *nwaves);
 /* Average time (ms) of `iters` back-to-back runs of one stage on its own stream: 1 pair search,
  * 2 PME chain, 3 bonded + exclusion kernels, 4 update + constraints, 5 prepare, 6 PME spread.

@@ -36,10 +36,9 @@ __device__ __forceinline__ void outer_acc(float *v9, float3 d, float3 f)
 }
 
 template <bool ENERGY>
-__global__ __launch_bounds__(256) void k_bonds(int n, const int2 *__restrict__ ij, const float2 *__restrict__ p,
+__device__ __forceinline__ void d_bonds(int t, int n, const int2 *__restrict__ ij, const float2 *__restrict__ p,
                                                const float4 *__restrict__ x, float *__restrict__ f, DevState *dw)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
     double e = 0.0; float v9[9] = { 0 };
     if (t < n) {
         const int2 a = ij[t]; const float2 par = p[t];
@@ -54,10 +53,9 @@ __global__ __launch_bounds__(256) void k_bonds(int n, const int2 *__restrict__ i
 }
 
 template <bool ENERGY>
-__global__ __launch_bounds__(256) void k_angles(int n, const int4 *__restrict__ ijk, const float2 *__restrict__ p,
+__device__ __forceinline__ void d_angles(int t, int n, const int4 *__restrict__ ijk, const float2 *__restrict__ p,
                                                 const float4 *__restrict__ x, float *__restrict__ f, DevState *dw)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
     double e = 0.0; float v9[9] = { 0 };
     if (t < n) {
         const int4 a = ijk[t]; const float2 par = p[t]; // theta0 (rad), k
@@ -80,10 +78,9 @@ __global__ __launch_bounds__(256) void k_angles(int n, const int4 *__restrict__ 
 }
 
 template <bool ENERGY>
-__global__ __launch_bounds__(256) void k_dihedrals(int n, const int4 *__restrict__ ijkl, const float4 *__restrict__ p,
+__device__ __forceinline__ void d_dihedrals(int t, int n, const int4 *__restrict__ ijkl, const float4 *__restrict__ p,
                                                    const float4 *__restrict__ x, float *__restrict__ f, DevState *dw)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
     double e = 0.0; float v9[9] = { 0 };
     if (t < n) {
         const int4 a = ijkl[t]; const float4 par = p[t]; // phi0 (rad), k, mult
@@ -116,10 +113,9 @@ __global__ __launch_bounds__(256) void k_dihedrals(int n, const int4 *__restrict
 }
 
 template <bool ENERGY>
-__global__ __launch_bounds__(256) void k_pairs14(int n, const int2 *__restrict__ ij, const float4 *__restrict__ p,
+__device__ __forceinline__ void d_pairs14(int t, int n, const int2 *__restrict__ ij, const float4 *__restrict__ p,
                                                  const float4 *__restrict__ x, float *__restrict__ f, DevState *dw)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
     double e = 0.0, e2 = 0.0; float v9[9] = { 0 };
     if (t < n) {
         const int2 a = ij[t]; const float4 par = p[t]; // c6, c12, qq*ONE_4PI_EPS0
@@ -136,11 +132,10 @@ __global__ __launch_bounds__(256) void k_pairs14(int n, const int2 *__restrict__
 }
 
 template <bool ENERGY>
-__global__ __launch_bounds__(256) void k_posres(int n, const int *__restrict__ idx, const float4 *__restrict__ ref,
+__device__ __forceinline__ void d_posres(int t, int n, const int *__restrict__ idx, const float4 *__restrict__ ref,
                                                 const float4 *__restrict__ kk, const float4 *__restrict__ x,
                                                 float *__restrict__ f, DevState *dw)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
     double e = 0.0; float v9[9] = { 0 };
     if (t < n) {
         const int a = idx[t];
@@ -154,24 +149,50 @@ __global__ __launch_bounds__(256) void k_posres(int n, const int *__restrict__ i
     if (ENERGY) accum_ev(e, v9, dw, MDX_E_POSRES);
 }
 
-#define LAUNCH_EV(kern, n, ...)                                                                     \
-    if ((n) > 0) {                                                                                  \
-        const int nb_ = ((n) + 255) / 256;                                                          \
-        if (energy) hipLaunchKernelGGL(kern<true>, dim3(nb_), dim3(256), 0, (s->bond_on_main ? s->stream : s->st_bond), n, __VA_ARGS__); \
-        else hipLaunchKernelGGL(kern<false>, dim3(nb_), dim3(256), 0, (s->bond_on_main ? s->stream : s->st_bond), n, __VA_ARGS__);   \
-    }
+// All bonded-type terms in one launch: consecutive ranges of workgroups serve bonds, angles, dihedrals,
+// 1-4 pairs and position restraints (a workgroup is homogeneous, so the energy reductions stay per type).
+// Five dependent launches of a few thousand threads each cost several times their arithmetic.
+struct BondedArgs {
+    int nb[5];                  // first workgroup of each type's range, then the end: nb[k] .. nb[k+1] (nb[5] = total in `nblocks`)
+    int nblocks;
+    int nbonds; const int2 *bond_ij; const float2 *bond_p;
+    int nangles; const int4 *angle_ijk; const float2 *angle_p;
+    int ndih; const int4 *dih_ijkl; const float4 *dih_p;
+    int npairs; const int2 *pair_ij; const float4 *pair_p;
+    int nposres; const int *posres_idx; const float4 *posres_ref; const float4 *posres_k;
+    const float4 *x; float *f; DevState *dw;
+};
+
+template <bool ENERGY>
+__global__ __launch_bounds__(256) void k_bonded(BondedArgs A)
+{
+    MDX_STAMP(A.dw, 10);
+    const int b = blockIdx.x;
+    if (b < A.nb[1]) d_bonds<ENERGY>((b - A.nb[0]) * 256 + threadIdx.x, A.nbonds, A.bond_ij, A.bond_p, A.x, A.f, A.dw);
+    else if (b < A.nb[2]) d_angles<ENERGY>((b - A.nb[1]) * 256 + threadIdx.x, A.nangles, A.angle_ijk, A.angle_p, A.x, A.f, A.dw);
+    else if (b < A.nb[3]) d_dihedrals<ENERGY>((b - A.nb[2]) * 256 + threadIdx.x, A.ndih, A.dih_ijkl, A.dih_p, A.x, A.f, A.dw);
+    else if (b < A.nb[4]) d_pairs14<ENERGY>((b - A.nb[3]) * 256 + threadIdx.x, A.npairs, A.pair_ij, A.pair_p, A.x, A.f, A.dw);
+    else d_posres<ENERGY>((b - A.nb[4]) * 256 + threadIdx.x, A.nposres, A.posres_idx, A.posres_ref, A.posres_k, A.x, A.f, A.dw);
+}
 
 int mdx_launch_bonded(mdx_system *s, bool energy, unsigned flags)
 {
-    if (flags & MDX_F_BONDED) {
-        LAUNCH_EV(k_bonds, s->nbonds, s->bond_ij, s->bond_p, s->x, s->f, s->d);
-        LAUNCH_EV(k_angles, s->nangles, s->angle_ijk, s->angle_p, s->x, s->f, s->d);
-        LAUNCH_EV(k_dihedrals, s->ndih, s->dih_ijkl, s->dih_p, s->x, s->f, s->d);
-        LAUNCH_EV(k_pairs14, s->npairs, s->pair_ij, s->pair_p, s->x, s->f, s->d);
-    }
-    if (flags & MDX_F_POSRES) {
-        LAUNCH_EV(k_posres, s->nposres, s->posres_idx, s->posres_ref, s->posres_k, s->x, s->f, s->d);
-    }
+    BondedArgs A;
+    const bool bo = (flags & MDX_F_BONDED) != 0, pr = (flags & MDX_F_POSRES) != 0;
+    A.nbonds = bo ? s->nbonds : 0; A.bond_ij = s->bond_ij; A.bond_p = s->bond_p;
+    A.nangles = bo ? s->nangles : 0; A.angle_ijk = s->angle_ijk; A.angle_p = s->angle_p;
+    A.ndih = bo ? s->ndih : 0; A.dih_ijkl = s->dih_ijkl; A.dih_p = s->dih_p;
+    A.npairs = bo ? s->npairs : 0; A.pair_ij = s->pair_ij; A.pair_p = s->pair_p;
+    A.nposres = pr ? s->nposres : 0; A.posres_idx = s->posres_idx; A.posres_ref = s->posres_ref; A.posres_k = s->posres_k;
+    A.x = s->x; A.f = s->f; A.dw = s->d;
+    const int cnt[5] = { A.nbonds, A.nangles, A.ndih, A.npairs, A.nposres };
+    int acc = 0;
+    for (int k = 0; k < 5; k++) { A.nb[k] = acc; acc += (cnt[k] + 255) / 256; }
+    A.nblocks = acc;
+    if (acc == 0) return MDX_OK;
+    hipStream_t st = s->bond_on_main ? s->stream : s->st_bond;
+    if (energy) hipLaunchKernelGGL(k_bonded<true>, dim3(acc), dim3(256), 0, st, A);
+    else hipLaunchKernelGGL(k_bonded<false>, dim3(acc), dim3(256), 0, st, A);
     // the Ewald correction of excluded pairs is evaluated by the nonbonded kernel on the pair list
     MDX_CHECK(s, hipGetLastError());
     return MDX_OK;

@@ -67,7 +67,8 @@ extern "C" mdx_system *mdx_create(int device, int natoms)
               hipStreamCreateWithPriority(&s->st_bond, hipStreamDefault, prio_greatest) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_pme, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
-              hipEventCreateWithFlags(&s->ev_bond, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
+              hipEventCreateWithFlags(&s->ev_bond, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
+              hipEventCreateWithFlags(&s->ev_spread, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
     const int n = natoms;
     s->ncol_cap = n / 128 + 256;
     s->npad = ((n + 63) / 64 + s->ncol_cap) * 64;
@@ -125,6 +126,7 @@ extern "C" void mdx_destroy(mdx_system *s)
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->ev_pme) (void)hipEventDestroy(s->ev_pme);
     if (s->ev_bond) (void)hipEventDestroy(s->ev_bond);
+    if (s->ev_spread) (void)hipEventDestroy(s->ev_spread);
     if (s->st_pme) (void)hipStreamDestroy(s->st_pme);
     if (s->st_bond) (void)hipStreamDestroy(s->st_bond);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -706,9 +708,11 @@ extern "C" int mdx_step(mdx_system *s, long long nsteps)
         // an event recorded by a separate marker costs the main stream several microseconds)
         if ((rc = mdx_launch_prepare(s, !forked_early))) return rc;
         // the nonbonded kernel is the critical path: enqueue it first, the side streams fill in
+        const bool spread_main = s->spread_on_main != 0;
+        if (spread_main) if ((rc = mdx_launch_pme_spread(s, s->stream, true))) return rc;
         if ((rc = mdx_launch_nonbonded(s, need_vir, MDX_F_NONBONDED | (s->have_pme ? MDX_F_EXCL : 0)))) return rc;
-        if ((rc = mdx_launch_pme(s, need_vir))) return rc;
-        if ((s->dbg & 1024) && !need_vir) if ((rc = mdx_launch_pme(s, need_vir))) return rc;         // timing experiment: the (idempotent) PME chain twice
+        if ((rc = mdx_launch_pme(s, need_vir, spread_main))) return rc;
+        if ((s->dbg & 1024) && !need_vir) if ((rc = mdx_launch_pme(s, need_vir, false))) return rc;         // timing experiment: the (idempotent) PME chain twice
         if ((rc = mdx_launch_bonded(s, need_vir, MDX_F_BONDED | MDX_F_POSRES))) return rc;
         if (s->pull_on) {
             const bool log_now = (step % s->pull_nstout == 0);

@@ -60,9 +60,29 @@ struct DevState {
     double vir_rep[64][9];
     double ekt_rep[64][9];
     unsigned long long npairs_rep[64][2];
+    long long ts_min[24], ts_max[24];   // diagnostic build (-DMDX_STAMPS): first start and last end of each kernel, 100 MHz clock
 };
 #define MDX_NREP 64
 #ifdef __HIPCC__
+// Diagnostic build only: every workgroup records when it starts and ends, per kernel id, so that one step's
+// real timeline can be read without a tracing tool between the streams.
+#ifdef MDX_STAMPS
+struct MdxStamp {
+    long long *mx;
+    // first workgroup stamps the start, the last one (by index: about the last to be dispatched) the end; plain
+    // stores, because thousands of workgroups updating one address would themselves stretch the kernel
+    __device__ MdxStamp(const DevState *d, int id) {
+        DevState *w = const_cast<DevState *>(d);
+        mx = nullptr;
+        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) w->ts_min[id] = (long long)wall_clock64();
+        if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1) mx = &w->ts_max[id];
+    }
+    __device__ ~MdxStamp() { if (mx) *mx = (long long)wall_clock64(); }
+};
+#define MDX_STAMP(d, id) MdxStamp stamp_((d), (id))
+#else
+#define MDX_STAMP(d, id)
+#endif
 __device__ __forceinline__ int mdx_rep() { return (int)((blockIdx.x + 5u * blockIdx.y) & (MDX_NREP - 1)); }
 #define MDX_ENER(dw, t) ((dw)->ener_rep[mdx_rep()][t])
 #define MDX_VIR(dw, k) ((dw)->vir_rep[mdx_rep()][k])
@@ -88,6 +108,7 @@ struct mdx_system {
     int dbg = 0;                       // diagnostic ablation bits (mdx_debug_set key 2)
     int nb_dyn = 1;                    // nonbonded kernel: rounds' worth of cheap units scheduled dynamically (mdx_debug_set key 3)
     int nb_dyn_split = 0;              // ... in 2^nb_dyn_split parts per unit (mdx_debug_set key 4)
+    int spread_on_main = 0;            // charge spreading on the main stream ahead of the nonbonded kernel: measured slower (mdx_debug_set key 7)
     int bond_on_main = 0;              // bonded and pull kernels behind the nonbonded kernel on the main stream (mdx_debug_set key 6)
     int early_fork = 1;                // release the side streams of a plain step right after the previous update (mdx_debug_set key 5)
     long long *nb_wave_t = nullptr;    // diagnostic per-wave clock buffer (mdx_debug_wave_times)
@@ -95,7 +116,7 @@ struct mdx_system {
     hipStream_t stream = nullptr;      // main stream: search, nonbonded, update
     hipStream_t st_pme = nullptr;      // PME chain (spread, FFTs, solve, gather) overlaps the nonbonded kernel
     hipStream_t st_bond = nullptr;     // bonded, restraint, exclusion and pull kernels
-    hipEvent_t ev_fork = nullptr, ev_pme = nullptr, ev_bond = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_pme = nullptr, ev_bond = nullptr, ev_spread = nullptr;
     float *f_pme = nullptr;            // 3N mesh forces (plain stores, so no race with the atomics on f)
     std::string err;
     int n = 0;                    // atoms
@@ -217,7 +238,8 @@ int mdx_fork(mdx_system *s);
 int mdx_join(mdx_system *s);
 int mdx_launch_prepare(mdx_system *s, bool fork = false);
 int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms);
-int mdx_launch_pme(mdx_system *s, bool energy);
+int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done = false);
+int mdx_launch_pme_spread(mdx_system *s, hipStream_t st, bool signal);
 int mdx_launch_bonded(mdx_system *s, bool energy, unsigned flags);
 int mdx_launch_pull(mdx_system *s, bool log_now, bool energy);
 int mdx_launch_update(mdx_system *s, bool do_tc, bool do_pr, bool virial);

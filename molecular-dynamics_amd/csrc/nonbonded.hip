@@ -80,6 +80,7 @@ __device__ __forceinline__ float mdx_pmecorr(float w)
 template <bool ENERGY, bool TIMED = false, int ABL = 0>
 __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nullptr)
 {
+    MDX_STAMP(A.dw, ENERGY ? 2 : 1);
     long long t_start = 0, w_start = 0; int n_units = 0, n_entries = 0;
     if (TIMED) { t_start = clock64(); w_start = wall_clock64(); }
     const int lane = threadIdx.x & 63;
@@ -462,11 +463,27 @@ extern "C" int mdx_debug_wave_times(mdx_system *s, long long *out, int max_waves
     return rc;
 }
 
+// Diagnostic (library built with -DMDX_STAMPS): reset == 1 enqueues a reset of the kernel time stamps on the main
+// stream; otherwise waits for the device and copies first-start / last-end of the 24 kernel ids (100 MHz ticks).
+extern "C" int mdx_debug_stamps(mdx_system *s, int reset, long long *out48)
+{
+    (void)hipSetDevice(s->device);
+    if (reset) {
+        MDX_CHECK(s, hipMemsetAsync((char *)s->d + offsetof(DevState, ts_min), 0x7f, sizeof(long long) * 24, s->stream));
+        MDX_CHECK(s, hipMemsetAsync((char *)s->d + offsetof(DevState, ts_max), 0, sizeof(long long) * 24, s->stream));
+        return MDX_OK;
+    }
+    MDX_CHECK(s, hipDeviceSynchronize());
+    MDX_CHECK(s, hipMemcpy(out48, (char *)s->d + offsetof(DevState, ts_min), sizeof(long long) * 48, hipMemcpyDeviceToHost));
+    return MDX_OK;
+}
+
 extern "C" int mdx_debug_set(mdx_system *s, int key, int value)
 {
     if (key == 1) { s->nb_variant = value; return MDX_OK; }
     if (key == 2) { s->dbg = value; return MDX_OK; }
     if (key == 3) { s->nb_dyn = value; return MDX_OK; }
+    if (key == 7) { s->spread_on_main = value; return MDX_OK; }
     if (key == 6) { s->bond_on_main = value; return MDX_OK; }
     if (key == 5) { s->early_fork = value; return MDX_OK; }
     if (key == 4 && value >= 0 && value <= 3) { s->nb_dyn_split = value; return MDX_OK; }

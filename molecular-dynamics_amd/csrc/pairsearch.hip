@@ -238,6 +238,7 @@ struct ListArgs {
 // once per lattice shift so the entries of a (super-cluster, shift) stay contiguous.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_build_list(ListArgs A)
 {
+    MDX_STAMP(A.d, 17);
     __shared__ float4 xi_sh[64];
     __shared__ int orig_sh[64];
     __shared__ NbEntry ebuf[EBUF];
@@ -518,6 +519,7 @@ __global__ void k_prepare(int npad, DevState *__restrict__ d, const float4 *__re
                           const int *__restrict__ shift_s, float4 *__restrict__ xq_s, float *__restrict__ f_s,
                           int nshift, const int3 *__restrict__ shift_ijk, float4 *__restrict__ shiftvec)
 {
+    MDX_STAMP(d, 0);
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const float *h = d->box.h;
     if (g < 8) d->nb_head[g * 32] = 0;       // unit queues of the nonbonded kernel

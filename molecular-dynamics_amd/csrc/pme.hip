@@ -70,6 +70,7 @@ struct SpreadArgs {
 // window (an atom that drifted far since the last pair search) goes straight to global memory.
 __global__ __launch_bounds__(256) void k_pme_spread_col(SpreadArgs A, const DevState *__restrict__ d)
 {
+    MDX_STAMP(d, 3);
     extern __shared__ float tile[];
     int *ox = (int *)(tile + A.ppc * A.T1 * A.T0);
     int *oy = ox + A.ppc;
@@ -275,6 +276,7 @@ __device__ __forceinline__ void dft_lines(float2 *a, float2 *b, const float2 *W,
 template <int MODE, bool ENERGY>
 __global__ __launch_bounds__(256) void k_pme_fft(FftArgs A)
 {
+    MDX_STAMP(A.d, 4 + MODE);
     extern __shared__ float2 fsm[];
     const int N = A.N, stride = N + 1, nl = A.nl;
     float2 *Wl = fsm, *a = fsm + N, *b = a + nl * stride;
@@ -391,6 +393,7 @@ static bool fft_split(int N, int &N1, int &N2)
 __global__ __launch_bounds__(256) void k_pme_gather(int n, const float4 *__restrict__ x, const DevState *__restrict__ d,
                                                     int K0, int K1, int K2, const float *__restrict__ phi, float *__restrict__ f)
 {
+    MDX_STAMP(d, 9);
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const int atom = g >> 4, sub = g & 15;
     float gx = 0.0f, gy = 0.0f, gz = 0.0f;
@@ -492,14 +495,15 @@ void mdx_pme_free(mdx_system *s)
     s->have_pme = false;
 }
 
-int mdx_launch_pme(mdx_system *s, bool energy)
+// Zero the charge grid and spread onto it, on stream `st`. With `signal` the spread kernel's completion
+// releases the PME stream (the spread then ran on the main stream, ahead of the nonbonded kernel and at
+// the full width of the GPU, instead of competing with that kernel for LDS and wave slots).
+int mdx_launch_pme_spread(mdx_system *s, hipStream_t st, bool signal)
 {
     if (!s->have_pme) return MDX_OK;
     const int K0 = s->K[0], K1 = s->K[1], K2 = s->K[2];
     const size_t nr = (size_t)K0 * K1 * K2;
-    const size_t ncx = (size_t)K2 * K1 * (K0 / 2 + 1);
-    MDX_CHECK(s, hipMemsetAsync(s->grid, 0, sizeof(float) * nr, s->st_pme));
-    const int nb = (int)(((size_t)s->n * 16 + 255) / 256);
+    MDX_CHECK(s, hipMemsetAsync(s->grid, 0, sizeof(float) * nr, st));
     {
         // window sizes from the column geometry (host copy of the box; a drift margin covers the rest)
         const double *bxd = s->h->boxd;
@@ -519,8 +523,20 @@ int mdx_launch_pme(mdx_system *s, bool energy)
         A.delta = (float)delta; A.grid = s->grid;
         if (getenv("MDX_PME_NOTILE")) { A.T0 = 4; A.T1 = 4; }
         const size_t lds = (size_t)A.ppc * A.T0 * A.T1 * 4 + (size_t)A.ppc * 8;
-        hipLaunchKernelGGL(k_pme_spread_col, dim3(s->ncx * s->ncy, nchunk), dim3(256), lds, s->st_pme, A, s->d);
+        hipExtLaunchKernelGGL(k_pme_spread_col, dim3(s->ncx * s->ncy, nchunk), dim3(256), lds, st, nullptr, signal ? s->ev_spread : nullptr, 0, A, (const DevState *)s->d);
+        MDX_CHECK(s, hipGetLastError());
+        if (signal) MDX_CHECK(s, hipStreamWaitEvent(s->st_pme, s->ev_spread, 0));
     }
+    return MDX_OK;
+}
+
+int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done)
+{
+    if (!s->have_pme) return MDX_OK;
+    const int K0 = s->K[0], K1 = s->K[1], K2 = s->K[2];
+    const size_t ncx = (size_t)K2 * K1 * (K0 / 2 + 1);
+    const int nb = (int)(((size_t)s->n * 16 + 255) / 256);
+    if (!spread_done) { int rc = mdx_launch_pme_spread(s, s->st_pme, false); if (rc) return rc; }
     if (s->dbg & 256) { MDX_CHECK(s, hipGetLastError()); return MDX_OK; }       // diagnostic: spreading only
     if (s->own_fft && !(s->dbg & 512)) {
         FftArgs F;

@@ -14,6 +14,7 @@ __global__ __launch_bounds__(256) void k_leapfrog(int n, const float4 *__restric
                                                   const int *__restrict__ tcgrp, const DevState *__restrict__ d, float dt,
                                                   int use_lambda, int use_pr)
 {
+    MDX_STAMP(d, 11);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 xi = x[i];
@@ -51,6 +52,7 @@ __global__ __launch_bounds__(256) void k_settle(int nw, const int4 *__restrict__
                                                 float4 *__restrict__ xp, float4 *__restrict__ v, float doh, float dhh,
                                                 float inv_dt, DevState *dw)
 {
+    MDX_STAMP(dw, 12);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     float v9[9] = { 0 };
     if (t < nw) {
@@ -134,6 +136,7 @@ __global__ __launch_bounds__(128) void k_lincs(int comp0, int ncomp, const int *
                                                const float *__restrict__ clen, const float4 *__restrict__ x, float4 *__restrict__ xp,
                                                float4 *__restrict__ v, int order, int niter, float inv_dt, DevState *dw)
 {
+    MDX_STAMP(dw, 13);
     const int t = comp0 + blockIdx.x * blockDim.x + threadIdx.x;
     float v9[9] = { 0 };
     if (t < comp0 + ncomp) {
@@ -263,6 +266,7 @@ __global__ __launch_bounds__(256) void k_ke(int n, const float4 *__restrict__ v,
 __global__ void k_tcouple(DevState *dw, int ntc, const double *ref_t, const double *tau_t, const double *ndf,
                           double dt_tc, unsigned long long seed, long long step)
 {
+    MDX_STAMP(dw, 15);
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     for (int g = 0; g < ntc; g++) {
         const double ek = dw->ekinh[g];

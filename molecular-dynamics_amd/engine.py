@@ -28,7 +28,7 @@ SYMBOLS = [
     "mdx_set_pcoupl", "mdx_set_dispcorr", "mdx_set_pull", "mdx_set_state", "mdx_set_state_device", "mdx_get_state",
     "mdx_get_step", "mdx_compute_forces", "mdx_get_forces", "mdx_get_energies", "mdx_get_virial", "mdx_step",
     "mdx_synchronize", "mdx_get_list_stats", "mdx_pop_energy_frames", "mdx_pop_pull_records",
-    "mdx_enable_kernel_timing", "mdx_get_kernel_timing", "mdx_debug_time_nonbonded", "mdx_debug_set", "mdx_debug_wave_times",
+    "mdx_enable_kernel_timing", "mdx_get_kernel_timing", "mdx_debug_time_nonbonded", "mdx_debug_set", "mdx_debug_wave_times", "mdx_debug_stamps",
     "mdx_debug_time_stage", "mdx_set_step", "mdx_generate_velocities", "mdx_constrain_start", "mdx_minimize",
     "mdx_frame_ring", "mdx_capture_frame", "mdx_frame_wait",
 ]
@@ -44,7 +44,7 @@ def load_library(path: str | None = None):
     global _LIB
     if _LIB is not None and path is None:
         return _LIB
-    p = path or LIB_PATH
+    p = path or os.environ.get("MDX_LIB") or LIB_PATH
     if not os.path.exists(p):
         raise MdxError(f"{p} not found: build it with `make -C molecular-dynamics_amd/csrc` "
                        "(the engine has no CPU fallback)")
@@ -90,6 +90,7 @@ def load_library(path: str | None = None):
     L.mdx_debug_time_nonbonded.argtypes = [vp, c_int, c_int, dp]
     L.mdx_debug_set.argtypes = [vp, c_int, c_int]
     L.mdx_debug_wave_times.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong), c_int, ctypes.POINTER(c_int)]
+    L.mdx_debug_stamps.argtypes = [vp, c_int, ctypes.POINTER(ctypes.c_longlong)]
     L.mdx_debug_time_stage.argtypes = [vp, c_int, c_int, dp]
     L.mdx_set_step.argtypes = [vp, ctypes.c_longlong]
     L.mdx_generate_velocities.argtypes = [vp, c_d, ctypes.c_ulonglong]
@@ -477,6 +478,11 @@ class Engine:
         buf = np.zeros((4096, 8), dtype=np.int64); nw = ctypes.c_int(0)
         self._call("mdx_debug_wave_times", buf.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), 4096, ctypes.byref(nw))
         return buf[:nw.value]
+
+    def debug_stamps(self, reset=False):
+        buf = np.zeros((2, 24), dtype=np.int64)
+        self._call("mdx_debug_stamps", 1 if reset else 0, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)))
+        return buf
 
     def debug_set(self, key, value):
         self._call("mdx_debug_set", int(key), int(value))

@@ -24,7 +24,7 @@ for a, b in zip(prep[-last-1:-1], prep[-last:]):
         (rows[b]["s"] - t0) / 1e3,
         start(lambda n: n.startswith("k_nonbonded")), end(lambda n: n.startswith("k_nonbonded")),
         start(lambda n: "k_pme_spread" in n), end(lambda n: "k_pme_spread" in n), end(lambda n: "k_pme_gather" in n),
-        start(lambda n: "k_bonds" in n), end(lambda n: "k_pairs14" in n or "k_dihedrals" in n or "k_posres" in n),
+        start(lambda n: "k_bonded" in n), end(lambda n: "k_bonded" in n),
         start(lambda n: n.startswith("k_leapfrog")), end(lambda n: "k_lincs" in n or "k_settle" in n)))
 print("%-10s %5s %7s | %7s %7s | %7s %7s %7s | %7s %7s | %7s %7s" % ("class", "n", "wall", "nb>", "nb<", "spread>", "spread<", "gather<", "bonded>", "bonded<", "update>", "update<"))
 import numpy as np
