@@ -192,6 +192,29 @@ long long mdx_pop_energy_frames(mdx_system *sys, double *out, long long max_fram
  * These are what PREFIX_pullx.xvg / PREFIX_pullf.xvg carry
  * (/root/reference/scripts/analyze_smd_trajectory.py:18-37). */
 long long mdx_pop_pull_records(mdx_system *sys, double *out, long long max_records);
+/* ---- Spatial domain decomposition over several devices: one process and one handle per GPU.
+ * No counterpart in the reference, which runs every gmx mdrun with a single rank
+ * (/root/reference/Snakefile:232-233: -ntmpi 1); serves the scaled synthetic water box.
+ * The handle is created over `capacity` atom slots filled with whole molecules of one kind (the per-slot
+ * pattern of mass, charge, LJ, exclusions and settles given through the setters above, no bonded terms).
+ * mdx_dd_load installs a partition: slots [0, n_home) are atoms this domain owns, [n_home, n_total) copies of
+ * atoms of other domains within the pair-list radius (halo: inverse mass zero, not spread onto the charge
+ * grid), the rest unused. x4 / v4 are device arrays of n_total float4 (xyz + anything). n_settle = home molecules,
+ * ndf = degrees of freedom of the home atoms, density = atoms per nm^3 of the whole system.
+ * A step then runs as: mdx_dd_pack (positions of listed home atoms into a send buffer) -> exchange by the
+ * caller -> mdx_dd_unpack (into halo slots) -> mdx_dd_step_begin -> mdx_dd_wait_spread -> caller sums the
+ * charge grid (mdx_dd_grid) over all domains -> mdx_dd_step_end. Pack/unpack/step calls enqueue on the handle's
+ * main stream; mdx_dd_stream_sync waits for it. */
+int mdx_dd_load(mdx_system *sys, int n_home, int n_total, const void *x4_dev, const void *v4_dev, int n_settle,
+                double ndf, double density);
+int mdx_dd_pack(mdx_system *sys, int n, const int *idx_dev, void *out4_dev);
+int mdx_dd_unpack(mdx_system *sys, int first_slot, int n, const void *in4_dev);
+int mdx_dd_step_begin(mdx_system *sys);
+int mdx_dd_wait_spread(mdx_system *sys);
+int mdx_dd_step_end(mdx_system *sys);
+int mdx_dd_grid(mdx_system *sys, void **grid_dev, long long *nelem);
+int mdx_dd_stream_sync(mdx_system *sys);
+int mdx_dd_state_pointers(mdx_system *sys, void **x4_dev, void **v4_dev);
 /* Time the nonbonded kernel with HIP events on the handle's stream (bench only). */
 int mdx_enable_kernel_timing(mdx_system *sys, int on);
 int mdx_get_kernel_timing(mdx_system *sys, double *nb_ms_total, long long *nb_launches);

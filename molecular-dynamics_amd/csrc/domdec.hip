@@ -1,0 +1,163 @@
+// Spatial domain decomposition of one large system over several GPUs (one process and one handle per GPU).
+//
+// Replaces what gmx mdrun's domain decomposition would do for a box too large for one device; the pipeline
+// itself only runs single-rank mdrun (/root/reference/Snakefile:232-233: -ntmpi 1), so this path serves the
+// scaled synthetic water box. A handle holds `ncap` atom slots filled with whole molecules of one kind
+// (the per-slot mass, charge and LJ pattern given at set-up repeats): first the molecules this domain owns
+// ("home"), then copies of the molecules of other domains within the pair-list radius of it ("halo"),
+// then unused slots. Halo atoms have inverse mass zero: they feel no update, take part in the short-range
+// kernels as partners of home atoms, and are skipped by the charge spreading (their owner spreads them).
+// Every periodic image is handled by the handle's own box, which is the box of the whole system.
+//   mdx_dd_load      install a new partition (home + halo state), every pair-list lifetime
+//   mdx_dd_pack      gather the positions of home atoms that are halo atoms elsewhere into a send buffer
+//   mdx_dd_unpack    scatter received halo positions into the halo slots
+//   mdx_dd_step_begin / mdx_dd_wait_spread / mdx_dd_step_end
+//                    a step in two halves; between them the caller sums the charge grids of all domains
+//                    (mdx_dd_grid gives the device pointer) so that every domain solves the full mesh problem
+#include "mdx_internal.h"
+
+int mdx_step_begin_internal(mdx_system *s);
+int mdx_step_end_internal(mdx_system *s);
+
+__global__ void k_dd_load(int ncap, int n_home, int n_total, const float4 *__restrict__ xin, const float4 *__restrict__ vin,
+                          const float *__restrict__ q0, const float *__restrict__ invm0, const float2 *__restrict__ lj0,
+                          float4 *__restrict__ x, float4 *__restrict__ v, float2 *__restrict__ lj)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncap) return;
+    if (i < n_total) {
+        const float4 p = xin[i];
+        x[i] = make_float4(p.x, p.y, p.z, q0[i]);
+        float4 w = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (i < n_home) { w = vin[i]; w.w = invm0[i]; }
+        v[i] = w;
+        lj[i] = lj0[i];
+    } else {
+        // unused slot: no charge, no LJ well, parked on top of a real atom (the kernels keep r = 0 finite)
+        const float4 p = xin[i % n_total];
+        x[i] = make_float4(p.x, p.y, p.z, 0.0f);
+        v[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        lj[i] = make_float2(lj0[i].x, 0.0f);
+    }
+}
+
+__global__ void k_dd_pack(int n, const int *__restrict__ idx, const float4 *__restrict__ x, float4 *__restrict__ out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = x[idx[k]];
+}
+
+__global__ void k_dd_unpack(int n, int first, const float4 *__restrict__ in, float4 *__restrict__ x)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float4 p = in[k];
+    const float q = x[first + k].w;
+    x[first + k] = make_float4(p.x, p.y, p.z, q);
+}
+
+extern "C" int mdx_dd_load(mdx_system *s, int n_home, int n_total, const void *x4_dev, const void *v4_dev, int n_settle,
+                           double ndf, double density)
+{
+    (void)hipSetDevice(s->device);
+    if (!(n_home >= 0 && n_home <= n_total && n_total >= 1 && n_total <= s->n) || !x4_dev || !v4_dev) {
+        s->err = "mdx_dd_load: need 0 <= n_home <= n_total <= capacity, n_total >= 1 and device buffers"; return MDX_ERR_ARG;
+    }
+    if (n_settle < 0 || n_settle > s->nsettle_cap) { s->err = "mdx_dd_load: more settles than were set up"; return MDX_ERR_ARG; }
+    if (s->ncons > 0 || s->nbonds > 0 || s->nangles > 0 || s->ndih > 0 || s->npairs > 0 || s->nposres > 0 || s->pull_on) {
+        s->err = "mdx_dd_load: the decomposed path carries rigid molecules of one kind only (no bonded terms, constraints or pull)";
+        return MDX_ERR_UNSUPPORTED;
+    }
+    if (!s->dd_q0) {
+        // the per-slot pattern as it was set up: charge, inverse mass, LJ parameters
+        MDX_CHECK(s, hipMalloc((void **)&s->dd_q0, sizeof(float) * s->n));
+        MDX_CHECK(s, hipMalloc((void **)&s->dd_invm0, sizeof(float) * s->n));
+        MDX_CHECK(s, hipMalloc((void **)&s->dd_lj0, sizeof(float2) * s->n));
+        MDX_CHECK(s, hipMemcpy(s->dd_q0, s->host_atoms.q.data(), sizeof(float) * s->n, hipMemcpyHostToDevice));
+        MDX_CHECK(s, hipMemcpy(s->dd_invm0, s->host_atoms.invm.data(), sizeof(float) * s->n, hipMemcpyHostToDevice));
+        MDX_CHECK(s, hipMemcpy(s->dd_lj0, s->lj, sizeof(float2) * s->n, hipMemcpyDeviceToDevice));
+    }
+    hipLaunchKernelGGL(k_dd_load, dim3((s->n + 255) / 256), dim3(256), 0, s->stream, s->n, n_home, n_total, (const float4 *)x4_dev,
+                       (const float4 *)v4_dev, (const float *)s->dd_q0, (const float *)s->dd_invm0, (const float2 *)s->dd_lj0, s->x, s->v, s->lj);
+    MDX_CHECK(s, hipGetLastError());
+    s->dd_on = true;
+    s->nsettle = n_settle;
+    s->search_density = density;
+    s->steps_since_search = 1 << 30;
+    s->forces_current = false;
+    s->ndf_total = ndf;
+    if (s->ntc == 1) {
+        s->ndf[0] = ndf;
+        MDX_CHECK(s, hipMemcpyAsync(s->d_tc + 2 * MDX_MAX_TC, &s->ndf[0], sizeof(double), hipMemcpyHostToDevice, s->stream));
+    } else if (s->ntc > 1) { s->err = "mdx_dd_load: one temperature-coupling group at most"; return MDX_ERR_UNSUPPORTED; }
+    return MDX_OK;
+}
+
+extern "C" int mdx_dd_pack(mdx_system *s, int n, const int *idx_dev, void *out4_dev)
+{
+    (void)hipSetDevice(s->device);
+    if (n <= 0) return MDX_OK;
+    hipLaunchKernelGGL(k_dd_pack, dim3((n + 255) / 256), dim3(256), 0, s->stream, n, idx_dev, (const float4 *)s->x, (float4 *)out4_dev);
+    MDX_CHECK(s, hipGetLastError());
+    return MDX_OK;
+}
+
+extern "C" int mdx_dd_unpack(mdx_system *s, int first, int n, const void *in4_dev)
+{
+    (void)hipSetDevice(s->device);
+    if (n <= 0) return MDX_OK;
+    if (first < 0 || first + n > s->n) { s->err = "mdx_dd_unpack: slot range outside the handle"; return MDX_ERR_ARG; }
+    hipLaunchKernelGGL(k_dd_unpack, dim3((n + 255) / 256), dim3(256), 0, s->stream, n, first, (const float4 *)in4_dev, s->x);
+    MDX_CHECK(s, hipGetLastError());
+    s->forces_current = false;
+    return MDX_OK;
+}
+
+extern "C" int mdx_dd_step_begin(mdx_system *s)
+{
+    (void)hipSetDevice(s->device);
+    if (!s->dd_on) { s->err = "mdx_dd_step_begin: no partition loaded"; return MDX_ERR_ARG; }
+    return mdx_step_begin_internal(s);
+}
+
+// Blocks until the charge spreading of the step begun last has finished (the grid may then be summed).
+extern "C" int mdx_dd_wait_spread(mdx_system *s)
+{
+    (void)hipSetDevice(s->device);
+    if (s->have_pme) MDX_CHECK(s, hipEventSynchronize(s->ev_spread));
+    return MDX_OK;
+}
+
+extern "C" int mdx_dd_step_end(mdx_system *s)
+{
+    (void)hipSetDevice(s->device);
+    if (!s->dd_on) { s->err = "mdx_dd_step_end: no partition loaded"; return MDX_ERR_ARG; }
+    return mdx_step_end_internal(s);
+}
+
+// Device pointer and element count of the real-space charge grid (x fastest), for the caller's sum over domains.
+extern "C" int mdx_dd_grid(mdx_system *s, void **grid_dev, long long *nelem)
+{
+    if (!s->have_pme) { s->err = "mdx_dd_grid: PME is not set up"; return MDX_ERR_ARG; }
+    if (grid_dev) *grid_dev = s->grid;
+    if (nelem) *nelem = (long long)s->K[0] * s->K[1] * s->K[2];
+    return MDX_OK;
+}
+
+// Blocks until the main stream is idle (packed buffers complete, state readable) without the checks and the
+// scalar read-back of mdx_synchronize.
+extern "C" int mdx_dd_stream_sync(mdx_system *s)
+{
+    (void)hipSetDevice(s->device);
+    MDX_CHECK(s, hipStreamSynchronize(s->stream));
+    return MDX_OK;
+}
+
+// Current device pointers of positions (float4: xyz, charge) and velocities (float4: xyz, inverse mass); they
+// change with every step (double buffering), so they are valid until the next step call only.
+extern "C" int mdx_dd_state_pointers(mdx_system *s, void **x4_dev, void **v4_dev)
+{
+    if (x4_dev) *x4_dev = s->x;
+    if (v4_dev) *v4_dev = s->v;
+    return MDX_OK;
+}

@@ -117,7 +117,7 @@ extern "C" void mdx_destroy(mdx_system *s)
                      s->col_count, s->col_astart, s->col_scstart, s->col_atoms, s->atom_col, s->atom_slot, s->wrapped, s->cj, s->work, s->work_order, s->sc_nwork,
                      s->exclmask, s->shift_ijk, s->shiftvec, s->bond_ij, s->bond_p, s->angle_ijk, s->angle_p, s->dih_ijkl, s->dih_p,
                      s->pair_ij, s->pair_p, s->posres_idx, s->posres_ref, s->posres_k, s->settle_idx, s->cons_ij, s->cons_len,
-                     s->comp_start, s->d_tc, s->pull_idx[0], s->pull_idx[1], s->gtab, s->d };
+                     s->comp_start, s->d_tc, s->pull_idx[0], s->pull_idx[1], s->gtab, s->dd_q0, s->dd_invm0, s->dd_lj0, s->d };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (s->h) (void)hipHostFree(s->h);
     if (s->ener_log) (void)hipHostFree(s->ener_log);
@@ -272,7 +272,7 @@ extern "C" int mdx_set_settles(mdx_system *s, int n, const int *idx, float doh, 
     int rc = check_idx(s, n, idx, 3, "mdx_set_settles"); if (rc) return rc;
     std::vector<int4> t(n);
     for (int a = 0; a < n; a++) t[a] = make_int4(idx[3 * a], idx[3 * a + 1], idx[3 * a + 2], 0);
-    s->nsettle = n; s->settle_doh = doh; s->settle_dhh = dhh;
+    s->nsettle = n; s->nsettle_cap = n; s->settle_doh = doh; s->settle_dhh = dhh;
     return dev_upload(s, &s->settle_idx, t);
 }
 
@@ -671,26 +671,20 @@ extern "C" int mdx_get_kernel_timing(mdx_system *s, double *ms, long long *launc
     return MDX_OK;
 }
 
-extern "C" int mdx_step(mdx_system *s, long long nsteps)
+// One MD step, or (domain decomposition) its two halves: phase 1 enqueues everything up to the charge
+// spreading and the short-range kernels and records ev_spread behind the spreading; the caller then sums the
+// charge grids of all domains; phase 2 enqueues the rest of the PME chain, the join, the update and the
+// coupling kernels. Phase 0 is the whole step. `more` tells that another step follows in the same call.
+static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early)
 {
-    (void)hipSetDevice(s->device);
-    ARG_CHECK(s, nsteps >= 0, "mdx_step: nsteps must be >= 0");
     int rc;
-    if (s->pull_on && s->pull_reset_pending) {
-        // the pull reference lives on the device; make sure the flag starts cleared
-        int zero = 0;
-        MDX_CHECK(s, hipMemcpyAsync(&s->d->pull_have_init, &zero, sizeof(int), hipMemcpyHostToDevice, s->stream));
-        MDX_CHECK(s, hipStreamSynchronize(s->stream));
-        s->pull_reset_pending = false;
-    }
-    bool forked_early = false;
-    for (long long it = 0; it < nsteps; it++) {
-        const long long step = s->step;
-        const bool do_search = s->steps_since_search >= s->nstlist;
-        const bool do_ener = s->nstcalcenergy > 0 && (step % s->nstcalcenergy == 0);
-        const bool do_pc = s->pcoupl != 0 && (step % s->nstpcouple == 0);
-        const bool need_vir = do_ener || do_pc;
-        const bool tc_apply = s->ntc > 0 && (step % s->nsttcouple == 0);
+    const long long step = s->step;
+    const bool do_search = s->steps_since_search >= s->nstlist;
+    const bool do_ener = s->nstcalcenergy > 0 && (step % s->nstcalcenergy == 0);
+    const bool do_pc = s->pcoupl != 0 && (step % s->nstpcouple == 0);
+    const bool need_vir = do_ener || do_pc;
+    const bool tc_apply = s->ntc > 0 && (step % s->nsttcouple == 0);
+    if (phase != 2) {
         if (s->first_step && s->ntc > 0) {
             if ((rc = mdx_launch_clear(s, false, true, false))) return rc;
             if ((rc = mdx_launch_ke(s, false, false))) return rc;
@@ -708,57 +702,86 @@ extern "C" int mdx_step(mdx_system *s, long long nsteps)
         // an event recorded by a separate marker costs the main stream several microseconds)
         if ((rc = mdx_launch_prepare(s, !forked_early))) return rc;
         // the nonbonded kernel is the critical path: enqueue it first, the side streams fill in
-        const bool spread_main = s->spread_on_main != 0;
+        const bool spread_main = s->spread_on_main != 0 && phase == 0;
         if (spread_main) if ((rc = mdx_launch_pme_spread(s, s->stream, true))) return rc;
         if ((rc = mdx_launch_nonbonded(s, need_vir, MDX_F_NONBONDED | (s->have_pme ? MDX_F_EXCL : 0)))) return rc;
-        if ((rc = mdx_launch_pme(s, need_vir, spread_main))) return rc;
-        if ((s->dbg & 1024) && !need_vir) if ((rc = mdx_launch_pme(s, need_vir, false))) return rc;         // timing experiment: the (idempotent) PME chain twice
+        if (phase == 0) {
+            if ((rc = mdx_launch_pme(s, need_vir, spread_main))) return rc;
+            if ((s->dbg & 1024) && !need_vir) if ((rc = mdx_launch_pme(s, need_vir, false))) return rc;         // timing experiment: the (idempotent) PME chain twice
+        } else if (s->have_pme) {
+            if ((rc = mdx_launch_pme_spread(s, s->st_pme, false))) return rc;
+            MDX_CHECK(s, hipEventRecord(s->ev_spread, s->st_pme));
+        }
         if ((rc = mdx_launch_bonded(s, need_vir, MDX_F_BONDED | MDX_F_POSRES))) return rc;
         if (s->pull_on) {
             const bool log_now = (step % s->pull_nstout == 0);
             if ((rc = mdx_launch_pull(s, log_now, need_vir))) return rc;
         }
-        if ((rc = mdx_join(s))) return rc;
-        if ((rc = mdx_launch_update(s, tc_apply, s->pcoupl == 2, need_vir))) return rc;
-        // The PME and bonded kernels of the next step read only the new positions (the spread goes through the
-        // sort permutation): when that step neither rebuilds the list nor accumulates energies they are
-        // released here, ahead of the thermostat kernels and the coordinate sort, instead of by the prepare kernel.
-        forked_early = false;
-        {
-            const long long nx = step + 1;
-            const bool vir_next = (s->nstcalcenergy > 0 && nx % s->nstcalcenergy == 0) || (s->pcoupl != 0 && nx % s->nstpcouple == 0);
-            const bool search_next = s->steps_since_search + 1 >= s->nstlist;
-            if (it + 1 < nsteps && !vir_next && !search_next && !do_pc && s->early_fork) {
-                MDX_CHECK(s, hipEventRecord(s->ev_fork, s->stream));
-                MDX_CHECK(s, hipStreamWaitEvent(s->st_pme, s->ev_fork, 0));
-                MDX_CHECK(s, hipStreamWaitEvent(s->st_bond, s->ev_fork, 0));
-                forked_early = true;
-            }
-        }
-        if (need_vir) {
-            if ((rc = mdx_launch_ke(s, false, true))) return rc;
-            if ((rc = mdx_launch_finish_energy(s))) return rc;
-            if (do_ener) {
-                if ((rc = record_energy_frame(s))) return rc;
-                frame_steps(s).push_back(step);
-            }
-        }
-        if (do_pc) if ((rc = mdx_launch_pcouple(s))) return rc;
-        if (s->ntc > 0 && ((step + 1) % s->nsttcouple == 0)) {
-            if (!need_vir) {
-                if ((rc = mdx_launch_clear(s, false, true, false))) return rc;
-                if ((rc = mdx_launch_ke(s, false, false))) return rc;
-            }
-            if ((rc = mdx_launch_tcouple(s))) return rc;
-        }
-        if (s->nstcomm > 0 && ((step + 1) % s->nstcomm == 0)) if ((rc = mdx_launch_comm(s))) return rc;
-        s->step++;
-        s->steps_since_search++;
-        s->forces_current = false;
-        if (s->time_nb && s->ev_pool.size() > 8192) if ((rc = drain_timing(s))) return rc;
+        if (phase == 1) return MDX_OK;
     }
+    if (phase == 2) if ((rc = mdx_launch_pme(s, need_vir, true))) return rc;
+    if ((rc = mdx_join(s))) return rc;
+    if ((rc = mdx_launch_update(s, tc_apply, s->pcoupl == 2, need_vir))) return rc;
+    // The PME and bonded kernels of the next step read only the new positions (the spread goes through the
+    // sort permutation): when that step neither rebuilds the list nor accumulates energies they are
+    // released here, ahead of the thermostat kernels and the coordinate sort, instead of by the prepare kernel.
+    forked_early = false;
+    {
+        const long long nx = step + 1;
+        const bool vir_next = (s->nstcalcenergy > 0 && nx % s->nstcalcenergy == 0) || (s->pcoupl != 0 && nx % s->nstpcouple == 0);
+        const bool search_next = s->steps_since_search + 1 >= s->nstlist;
+        if (phase == 0 && more && !vir_next && !search_next && !do_pc && s->early_fork) {
+            MDX_CHECK(s, hipEventRecord(s->ev_fork, s->stream));
+            MDX_CHECK(s, hipStreamWaitEvent(s->st_pme, s->ev_fork, 0));
+            MDX_CHECK(s, hipStreamWaitEvent(s->st_bond, s->ev_fork, 0));
+            forked_early = true;
+        }
+    }
+    if (need_vir) {
+        if ((rc = mdx_launch_ke(s, false, true))) return rc;
+        if ((rc = mdx_launch_finish_energy(s))) return rc;
+        if (do_ener) {
+            if ((rc = record_energy_frame(s))) return rc;
+            frame_steps(s).push_back(step);
+        }
+    }
+    if (do_pc) if ((rc = mdx_launch_pcouple(s))) return rc;
+    if (s->ntc > 0 && ((step + 1) % s->nsttcouple == 0)) {
+        if (!need_vir) {
+            if ((rc = mdx_launch_clear(s, false, true, false))) return rc;
+            if ((rc = mdx_launch_ke(s, false, false))) return rc;
+        }
+        if ((rc = mdx_launch_tcouple(s))) return rc;
+    }
+    if (s->nstcomm > 0 && ((step + 1) % s->nstcomm == 0)) if ((rc = mdx_launch_comm(s))) return rc;
+    s->step++;
+    s->steps_since_search++;
+    s->forces_current = false;
+    if (s->time_nb && s->ev_pool.size() > 8192) if ((rc = drain_timing(s))) return rc;
     return MDX_OK;
 }
+
+extern "C" int mdx_step(mdx_system *s, long long nsteps)
+{
+    (void)hipSetDevice(s->device);
+    ARG_CHECK(s, nsteps >= 0, "mdx_step: nsteps must be >= 0");
+    int rc;
+    if (s->pull_on && s->pull_reset_pending) {
+        // the pull reference lives on the device; make sure the flag starts cleared
+        int zero = 0;
+        MDX_CHECK(s, hipMemcpyAsync(&s->d->pull_have_init, &zero, sizeof(int), hipMemcpyHostToDevice, s->stream));
+        MDX_CHECK(s, hipStreamSynchronize(s->stream));
+        s->pull_reset_pending = false;
+    }
+    bool forked_early = false;
+    for (long long it = 0; it < nsteps; it++)
+        if ((rc = step_phase(s, 0, it + 1 < nsteps, forked_early))) return rc;
+    return MDX_OK;
+}
+
+// Domain decomposition: the two halves of a step around the summation of the charge grids (csrc/domdec.hip).
+int mdx_step_begin_internal(mdx_system *s) { bool fe = false; return step_phase(s, 1, false, fe); }
+int mdx_step_end_internal(mdx_system *s) { bool fe = false; return step_phase(s, 2, false, fe); }
 
 extern "C" long long mdx_pop_energy_frames(mdx_system *s, double *out, long long max_frames)
 {

@@ -179,6 +179,7 @@ struct mdx_system {
     int nposres = 0; int *posres_idx = nullptr; float4 *posres_ref = nullptr; float4 *posres_k = nullptr;
     int refcoord_scaling = 0;     // 0 no, 1 all, 2 com
     // constraints
+    int nsettle_cap = 0;          // settles set up (domain decomposition activates the first nsettle of them)
     int nsettle = 0; int4 *settle_idx = nullptr; float settle_doh = 0, settle_dhh = 0;
     int ncons = 0; int ncomp = 0; int ncomp_small = 0;   // components are sorted by size; the first ncomp_small have <= 4 constraints
     int2 *cons_ij = nullptr; float *cons_len = nullptr; int *comp_start = nullptr;  // constraints sorted by component
@@ -219,6 +220,10 @@ struct mdx_system {
     bool pme_signalled = false;        // ev_pme already attached to the last kernel of the PME chain
     bool time_nb = false; std::vector<hipEvent_t> ev_pool; std::vector<std::pair<int, int>> ev_nb;
     double nb_ms_total = 0; long long nb_launches = 0;
+    // domain decomposition (csrc/domdec.hip)
+    bool dd_on = false;
+    float *dd_q0 = nullptr, *dd_invm0 = nullptr; float2 *dd_lj0 = nullptr;   // per-slot pattern as set up
+    double search_density = 0.0;  // atoms per nm^3 for the sizing of the search grid (0: atoms / box volume)
     void *frame_ring = nullptr;   // pinned trajectory-frame slots (runctl.hip)
 };
 

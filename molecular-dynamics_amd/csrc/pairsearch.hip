@@ -603,11 +603,12 @@ int mdx_search(mdx_system *s)
     MDX_CHECK(s, hipMemcpyAsync(s->shift_ijk, s->h_shift_ijk.data(), sizeof(int3) * s->nshift, hipMemcpyHostToDevice, s->stream));
     // column grid: super-cluster cells roughly cubic
     const double vol = box[0] * box[4] * box[8];
-    const double dens = s->n / vol;
+    // (a decomposed domain fills part of the box only: its columns are sized by the density of the whole system)
+    const double dens = s->search_density > 0.0 ? s->search_density : s->n / vol;
     double side = cbrt(64.0 / dens);
     int ncx = (int)fmax(1.0, floor(box[0] / side)), ncy = (int)fmax(1.0, floor(box[4] / side));
     // keep the expected column population within the in-LDS sort capacity
-    while ((double)s->n / (ncx * ncy) > 0.55 * MDX_MAX_COL) { ncx++; ncy++; }
+    while (dens * vol / (ncx * ncy) > 0.55 * MDX_MAX_COL) { ncx++; ncy++; }
     while (ncx * ncy > s->ncol_cap) { if (ncx >= ncy) ncx--; else ncy--; }
     s->ncx = ncx; s->ncy = ncy;
     const int ncol = ncx * ncy;

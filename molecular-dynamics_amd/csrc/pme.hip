@@ -59,6 +59,7 @@ struct SpreadArgs {
     int ppc;             // tile planes per workgroup
     float delta;         // drift margin in nm used for the window origins
     float *grid;
+    const float4 *v_home;        // domain decomposition: velocities (w = inverse mass); atoms with w == 0 are halo copies and are not spread
 };
 
 // Charge spreading with one workgroup per (pair-search column, slab of grid planes).
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(256) void k_pme_spread_col(SpreadArgs A, const DevS
         if (A.perm[gs] < 0) continue;                       // filler slot of a padded cluster
         float4 p = A.x[A.perm_src[gs]];
         if (p.w == 0.0f) continue;
+        if (A.v_home && A.v_home[A.perm_src[gs]].w == 0.0f) continue;
         int sa, sb, sc;
         unpack_shift(A.shift_s[gs], sa, sb, sc);
         p.x += sa * bx.h[0] + sb * bx.h[3] + sc * bx.h[6];
@@ -520,7 +522,7 @@ int mdx_launch_pme_spread(mdx_system *s, hipStream_t st, bool signal)
         int nchunk = 1;
         while ((size_t)((planes + nchunk - 1) / nchunk) * A.T0 * A.T1 * 4 > 48 * 1024 || (s->ncx * s->ncy * nchunk < 512 && nchunk < 8)) nchunk++;
         A.ppc = (planes + nchunk - 1) / nchunk;
-        A.delta = (float)delta; A.grid = s->grid;
+        A.delta = (float)delta; A.grid = s->grid; A.v_home = s->dd_on ? s->v : nullptr;
         if (getenv("MDX_PME_NOTILE")) { A.T0 = 4; A.T1 = 4; }
         const size_t lds = (size_t)A.ppc * A.T0 * A.T1 * 4 + (size_t)A.ppc * 8;
         hipExtLaunchKernelGGL(k_pme_spread_col, dim3(s->ncx * s->ncy, nchunk), dim3(256), lds, st, nullptr, signal ? s->ev_spread : nullptr, 0, A, (const DevState *)s->d);

@@ -1,0 +1,356 @@
+"""Spatial domain decomposition of one large rigid-water system over several GPUs.
+
+One process per GPU (`torch.distributed`; backend "nccl" is RCCL over xGMI on ROCm), one engine handle
+per process. The reference pipeline never decomposes a system (every `gmx mdrun` runs with `-ntmpi 1`,
+/root/reference/Snakefile:232-233); this module serves the scaled synthetic water box only.
+
+Scheme (see csrc/domdec.hip for the device side):
+
+* The unit cell is cut into px x py x pz bricks in fractional coordinates. A molecule belongs to the brick
+  that holds its first atom. Every pair-list lifetime (`nstlist` steps) all ranks all-gather the home
+  molecules (positions, velocities, ids), re-assign them, and select their halo: molecules of other ranks whose
+  first atom lies within `rlist` + molecule size of the brick (a conservative test per fractional dimension,
+  so it holds in any triclinic cell). Because every rank sees all positions at that moment, it computes the
+  halo of every other rank too and so knows, without further messages, which of its home atoms it has to
+  send where on the following steps, and in which order they arrive.
+* Every other step: the positions of those atoms are packed on the device, exchanged point to point
+  (one batched send/recv group: `ncclSend`/`ncclRecv` under NCCL) and scattered into the halo slots.
+  Forces are not sent back: a pair across a boundary is evaluated by both owners, each keeping its own half.
+* PME: every rank spreads its home charges on a full-size grid, the grids are summed with one all-reduce,
+  and every rank solves the whole mesh problem and gathers forces for its home atoms.
+* The thermostat acts per domain (V-rescale with the domain's own degrees of freedom, as a temperature-
+  coupling group would); centre-of-mass motion removal and pressure coupling are off in this mode; energies
+  are not assembled across ranks.
+
+The partition arithmetic (`owner_of`, `halo_mask`, `plan_exchange`) is plain torch on whatever device the
+tensors live on, so it is tested on CPU tensors with a two-rank gloo group.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import units as U
+from .system import MDSystem
+
+MOL_ATOMS = 3           # rigid three-site water
+MOL_RADIUS = 0.11       # nm: no atom of a molecule is farther than this from its first atom
+
+
+# --------------------------------------------------------------------------------------------- partition arithmetic
+def rank_grid(world: int):
+    """px, py, pz with px*py*pz == world, as cubic as possible, in ascending order (x gets the fewest cuts)."""
+    best = (1, 1, world)
+    for a in range(1, world + 1):
+        if world % a:
+            continue
+        for b in range(1, world // a + 1):
+            if (world // a) % b:
+                continue
+            c = world // a // b
+            cand = tuple(sorted((a, b, c)))
+            if max(cand) - min(cand) < max(best) - min(best):
+                best = cand
+    return best  # ascending: x gets the smallest count
+
+
+def fractional(x: torch.Tensor, box: torch.Tensor) -> torch.Tensor:
+    """Fractional coordinates in [0, 1) of positions x (.., 3) in the cell with rows box[0..2]."""
+    s = x @ torch.linalg.inv(box)
+    return s - torch.floor(s)
+
+
+def owner_of(s_first: torch.Tensor, dims) -> torch.Tensor:
+    """Rank owning each molecule from the fractional coordinates (M, 3) of its first atom."""
+    d = torch.tensor(dims, device=s_first.device, dtype=s_first.dtype)
+    c = torch.minimum(torch.floor(s_first * d), d - 1).to(torch.int64)
+    return (c[:, 0] * dims[1] + c[:, 1]) * dims[2] + c[:, 2]
+
+
+def brick_of(rank: int, dims):
+    cz = rank % dims[2]; cy = (rank // dims[2]) % dims[1]; cx = rank // (dims[1] * dims[2])
+    lo = (cx / dims[0], cy / dims[1], cz / dims[2])
+    hi = ((cx + 1) / dims[0], (cy + 1) / dims[1], (cz + 1) / dims[2])
+    return lo, hi
+
+
+def fractional_margins(box: torch.Tensor, radius: float):
+    """Per dimension d, the largest change of the fractional coordinate s_d over a distance `radius`:
+    |grad s_d| = norm of column d of inv(box)."""
+    inv = torch.linalg.inv(box)
+    return [float(radius * torch.linalg.norm(inv[:, d])) for d in range(3)]
+
+
+def halo_mask(s_first: torch.Tensor, owner: torch.Tensor, rank: int, dims, margins) -> torch.Tensor:
+    """Molecules not owned by `rank` whose first atom is within the margins of its brick (periodic)."""
+    lo, hi = brick_of(rank, dims)
+    m = owner != rank
+    for d in range(3):
+        if dims[d] == 1 or (hi[d] - lo[d]) + 2 * margins[d] >= 1.0:
+            continue                      # the brick spans this dimension, or brick + margins wrap around: everything is near
+        c = 0.5 * (lo[d] + hi[d]); half = 0.5 * (hi[d] - lo[d])
+        dist_c = torch.abs(s_first[:, d] - c)
+        dist_c = torch.minimum(dist_c, 1.0 - dist_c)          # periodic distance to the brick centre
+        m = m & (dist_c < half + margins[d])
+    return m
+
+
+def plan_exchange(s_first, owner, rank, world, dims, margins):
+    """For rank `rank`: indices (into the gathered molecule order) of its home molecules, of its halo molecules
+    grouped by owner (ascending rank), and per destination the indices of its home molecules that the
+    destination holds as halo, in the destination's slot order."""
+    home = torch.nonzero(owner == rank).flatten()
+    recv = []
+    mine = halo_mask(s_first, owner, rank, dims, margins)
+    for src in range(world):
+        recv.append(torch.nonzero(mine & (owner == src)).flatten() if src != rank else home[:0])
+    send = []
+    for dst in range(world):
+        if dst == rank:
+            send.append(home[:0]); continue
+        theirs = halo_mask(s_first, owner, dst, dims, margins)
+        send.append(torch.nonzero(theirs & (owner == rank)).flatten())
+    return home, recv, send
+
+
+# --------------------------------------------------------------------------------------------- transport
+class Transport:
+    """Collectives on device tensors; with a gloo group the tensors are staged through the host (tests)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.staged = dist.is_initialized() and dist.get_backend(group) == "gloo"
+
+    def all_gather(self, t: torch.Tensor):
+        if self.world == 1:
+            return [t]
+        src = t.cpu() if self.staged else t
+        out = [torch.empty_like(src) for _ in range(self.world)]
+        dist.all_gather(out, src.contiguous(), group=self.group)
+        return [o.to(t.device) for o in out] if self.staged else out
+
+    def all_reduce_sum_(self, t: torch.Tensor):
+        if self.world == 1:
+            return t
+        if self.staged:
+            h = t.cpu()
+            dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, group=self.group)
+        return t
+
+    def exchange(self, send, recv):
+        """send[r] goes to rank r, recv[r] is filled from rank r (tensors, possibly empty); one batched group."""
+        if self.world == 1:
+            return
+        ops, stage = [], []
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            if recv[r].numel():
+                buf = torch.empty(recv[r].shape, dtype=recv[r].dtype) if self.staged else recv[r]
+                if self.staged:
+                    stage.append((recv[r], buf))
+                ops.append(dist.P2POp(dist.irecv, buf, r, self.group))
+            if send[r].numel():
+                ops.append(dist.P2POp(dist.isend, send[r].cpu() if self.staged else send[r], r, self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for dst, buf in stage:
+            dst.copy_(buf)
+
+
+class _DevArray:
+    """Wraps a raw device pointer for torch.as_tensor (CUDA array interface)."""
+
+    def __init__(self, ptr, shape, typestr="<f4"):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def _template(nmol: int, box: np.ndarray) -> MDSystem:
+    """`nmol` TIP3P slots (O, H, H) with exclusions and settles; positions are installed by mdx_dd_load."""
+    from . import synth
+    mass, q, sig, eps = synth._water_arrays(nmol)
+    n = MOL_ATOMS * nmol
+    idx = np.arange(n, dtype=np.int32).reshape(nmol, 3)
+    o, h1, h2 = idx[:, 0], idx[:, 1], idx[:, 2]
+    excl = np.stack([np.stack([h1, h2], 1), np.stack([o, h2], 1), np.stack([o, h1], 1)], 1).reshape(-1)
+    s = MDSystem(x=np.zeros((n, 3)), box=np.asarray(box, dtype=np.float64), mass=mass, charge=q, sigma=sig, eps=eps,
+                 molid=np.repeat(np.arange(nmol, dtype=np.int32), 3),
+                 excl_start=(2 * np.arange(n + 1)).astype(np.int32), excl_list=excl.astype(np.int32))
+    s.settles = idx.copy()
+    s.v = np.zeros((n, 3))
+    s.groups = {"System": np.arange(n, dtype=np.int32)}
+    return s
+
+
+# --------------------------------------------------------------------------------------------- the decomposed run
+class DecomposedWater:
+    """A rigid-water system (MDSystem whose molecules are consecutive O, H, H triples with settles) stepped on
+    `world` GPUs. Every rank constructs this object with the same global system."""
+
+    def __init__(self, sysm: MDSystem, device: int = 0, rc: float = 1.0, dt: float = 0.002, nstlist: int = 20,
+                 ref_t: float | None = 300.0, tau_t: float = 0.1, nsttcouple: int = 10, fourierspacing: float = 0.16,
+                 rlist: float | None = None, seed: int = 1, group=None, dims=None, nstcalcenergy: int = 0,
+                 shared_device: bool = False):
+        from . import engine as eng
+        self.tr = Transport(group)
+        self.rank, self.world = self.tr.rank, self.tr.world
+        self.dims = tuple(dims) if dims is not None else rank_grid(self.world)
+        assert self.dims[0] * self.dims[1] * self.dims[2] == self.world
+        n = sysm.natoms
+        assert n % MOL_ATOMS == 0 and len(sysm.settles) == n // MOL_ATOMS, "rigid three-site molecules only"
+        self.nmol = n // MOL_ATOMS
+        self.dev = torch.device("cuda", device)
+        self.box_np = np.asarray(sysm.box, dtype=np.float64)
+        self.box = torch.tensor(self.box_np, dtype=torch.float64, device=self.dev)
+        self.volume = float(abs(np.linalg.det(self.box_np)))
+        self.density = n / self.volume
+        self.nstlist = int(nstlist)
+        beta = U.ewald_beta(rc)
+        if rlist is None:
+            rlist = eng.verlet_buffer_rlist(sysm, rc, beta, nstlist, dt, ref_t or 300.0, 0.005)
+        self.rlist = float(rlist)
+        self.margins = fractional_margins(self.box, self.rlist + 2 * MOL_RADIUS + 0.02)
+        # capacities: home share with head room for density fluctuations, halo from the brick geometry
+        frac = [1.0 / d for d in self.dims]
+        grown = [min(1.0, f + 2 * m) if d > 1 else 1.0 for f, m, d in zip(frac, self.margins, self.dims)]
+        share = frac[0] * frac[1] * frac[2]
+        self.home_cap = int(self.nmol * share * 1.10) + 256
+        self.halo_cap = int(self.nmol * (grown[0] * grown[1] * grown[2] - share) * 1.10) + 256 if self.world > 1 else 0
+        self.cap = min(self.home_cap + self.halo_cap, self.nmol + 256)
+        tmpl = _template(self.cap, self.box_np)
+        grid = U.pme_grid(self.box_np, fourierspacing)
+        self.engine = eng.Engine(tmpl, rc=rc, rlist=self.rlist, dt=dt, nstlist=nstlist, pme=True, grid=grid, device=device,
+                                 tc_groups=["System"] if ref_t is not None else None, ref_t=[ref_t or 300.0], tau_t=[tau_t],
+                                 nsttcouple=nsttcouple, nstcalcenergy=nstcalcenergy, nstcomm=0, seed=seed + self.rank)
+        if shared_device:
+            # several ranks time-share one GPU (tests): the nonbonded kernel's ticket queues crawl under process
+            # switching, the static deal does not
+            self.engine.debug_set(3, 0)
+        gp, gn = self.engine.dd_grid()
+        self.grid_t = torch.as_tensor(_DevArray(gp, (gn,)), device=self.dev)
+        # initial home set from the given coordinates
+        x = torch.tensor(np.asarray(sysm.x, dtype=np.float32), device=self.dev).reshape(self.nmol, MOL_ATOMS, 3)
+        v = torch.tensor(np.asarray(sysm.v if sysm.v is not None else np.zeros((n, 3)), dtype=np.float32), device=self.dev).reshape(self.nmol, MOL_ATOMS, 3)
+        ids = torch.arange(self.nmol, device=self.dev, dtype=torch.int64)
+        own = owner_of(fractional(x[:, 0, :].double(), self.box), self.dims)
+        self._install(x, v, ids, own)
+        self.steps_since_partition = 0
+        self.nsteps_done = 0
+
+    # ------------------------------------------------------------------ partition
+    def _install(self, x_all, v_all, ids_all, own):
+        """Install home + halo from the gathered molecule arrays (M, 3, 3), (M, 3, 3), (M,), owner (M,)."""
+        s_first = fractional(x_all[:, 0, :].double(), self.box)
+        home, recv, send = plan_exchange(s_first, own, self.rank, self.world, self.dims, self.margins)
+        halo = torch.cat(recv) if self.world > 1 else home[:0]
+        nh, nl = int(home.numel()), int(halo.numel())
+        if nh + nl > self.cap:
+            raise RuntimeError(f"rank {self.rank}: {nh} home + {nl} halo molecules exceed the capacity {self.cap}")
+        if nh == 0:
+            raise RuntimeError(f"rank {self.rank}: empty domain")
+        order = torch.cat([home, halo])
+        x4 = torch.zeros((MOL_ATOMS * (nh + nl), 4), device=self.dev, dtype=torch.float32)
+        v4 = torch.zeros_like(x4)
+        x4[:, :3] = x_all[order].reshape(-1, 3)
+        v4[: MOL_ATOMS * nh, :3] = v_all[home].reshape(-1, 3)
+        self.ids_home = ids_all[home].clone()
+        self.n_home, self.n_halo = nh, nl
+        # exchange plan for the steps until the next partition, in atoms
+        def atoms_of(mols_local):           # local molecule slots -> atom slots
+            return (mols_local[:, None] * MOL_ATOMS + torch.arange(MOL_ATOMS, device=self.dev)[None, :]).reshape(-1)
+        # position of each gathered molecule in my home block
+        slot_of = torch.full((x_all.shape[0],), -1, device=self.dev, dtype=torch.int64)
+        slot_of[home] = torch.arange(nh, device=self.dev)
+        self.send_counts = [int(sd.numel()) * MOL_ATOMS for sd in send]
+        self.recv_counts = [int(rv.numel()) * MOL_ATOMS for rv in recv]
+        self.send_idx = atoms_of(torch.cat([slot_of[sd] for sd in send])).to(torch.int32).contiguous() if self.world > 1 else None
+        self.send_buf = torch.zeros((sum(self.send_counts), 4), device=self.dev, dtype=torch.float32)
+        self.recv_buf = torch.zeros((sum(self.recv_counts), 4), device=self.dev, dtype=torch.float32)
+        self._keep = (x4, v4)               # alive until the load kernel has run
+        torch.cuda.synchronize(self.dev)
+        ndf = 6.0 * nh                       # rigid three-site molecules, no centre-of-mass removal
+        self.engine.dd_load(MOL_ATOMS * nh, MOL_ATOMS * (nh + nl), x4.data_ptr(), v4.data_ptr(), nh, ndf, self.density)
+
+    def _home_state(self):
+        """(n_home, 3, 3) positions and velocities of the home molecules, read from the handle."""
+        self.engine.dd_stream_sync()
+        xp, vp = self.engine.dd_state_pointers()
+        na = MOL_ATOMS * self.n_home
+        x = torch.as_tensor(_DevArray(xp, (na, 4)), device=self.dev)[:, :3].clone().reshape(self.n_home, MOL_ATOMS, 3)
+        v = torch.as_tensor(_DevArray(vp, (na, 4)), device=self.dev)[:, :3].clone().reshape(self.n_home, MOL_ATOMS, 3)
+        return x, v
+
+    def _gather_all(self):
+        x, v = self._home_state()
+        pad = self.home_cap
+        if self.n_home > pad:
+            raise RuntimeError(f"rank {self.rank}: {self.n_home} home molecules exceed the gather slot {pad}")
+        rec = torch.zeros((pad, 18), device=self.dev, dtype=torch.float32)
+        rec[: self.n_home, :9] = x.reshape(self.n_home, 9); rec[: self.n_home, 9:] = v.reshape(self.n_home, 9)
+        ids = torch.full((pad,), -1, device=self.dev, dtype=torch.int64)
+        ids[: self.n_home] = self.ids_home
+        recs = torch.cat(self.tr.all_gather(rec)); idss = torch.cat(self.tr.all_gather(ids))
+        keep = idss >= 0
+        recs, idss = recs[keep], idss[keep]
+        return recs[:, :9].reshape(-1, 3, 3), recs[:, 9:].reshape(-1, 3, 3), idss
+
+    def repartition(self):
+        x_all, v_all, ids_all = self._gather_all()
+        own = owner_of(fractional(x_all[:, 0, :].double(), self.box), self.dims)
+        self._install(x_all, v_all, ids_all, own)
+        self.steps_since_partition = 0
+
+    def _refresh_halo(self):
+        if self.world == 1 or self.n_halo == 0 and sum(self.send_counts) == 0:
+            return
+        ns = sum(self.send_counts)
+        if ns:
+            self.engine.dd_pack(ns, self.send_idx.data_ptr(), self.send_buf.data_ptr())
+        self.engine.dd_stream_sync()
+        send = list(torch.split(self.send_buf, self.send_counts)); recv = list(torch.split(self.recv_buf, self.recv_counts))
+        self.tr.exchange(send, recv)
+        torch.cuda.synchronize(self.dev)
+        if self.n_halo:
+            self.engine.dd_unpack(MOL_ATOMS * self.n_home, MOL_ATOMS * self.n_halo, self.recv_buf.data_ptr())
+
+    # ------------------------------------------------------------------ stepping
+    def step(self, nsteps: int):
+        import os
+        dbg = bool(os.environ.get("MDX_DD_DEBUG"))
+        def say(what):
+            if dbg:
+                print("[dd rank %d step %d] %s" % (self.rank, self.nsteps_done, what), flush=True)
+        for _ in range(int(nsteps)):
+            if self.steps_since_partition >= self.nstlist:
+                say("repartition"); self.repartition()
+            elif self.steps_since_partition > 0:
+                say("halo refresh"); self._refresh_halo()
+            say("begin"); self.engine.dd_step_begin()
+            if self.world > 1:
+                say("wait spread"); self.engine.dd_wait_spread()
+                say("grid sum"); self.tr.all_reduce_sum_(self.grid_t)
+                torch.cuda.synchronize(self.dev)
+            say("end"); self.engine.dd_step_end()
+            self.steps_since_partition += 1
+            self.nsteps_done += 1
+
+    def synchronize(self):
+        self.engine.synchronize()
+
+    def gather_state(self):
+        """Positions and velocities of the whole system, (N, 3) each, in the original molecule order (every rank)."""
+        x_all, v_all, ids_all = self._gather_all()
+        order = torch.argsort(ids_all)
+        return x_all[order].reshape(-1, 3).cpu().numpy(), v_all[order].reshape(-1, 3).cpu().numpy()
+
+    def close(self):
+        self.engine.close()

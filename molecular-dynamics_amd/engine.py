@@ -29,6 +29,8 @@ SYMBOLS = [
     "mdx_get_step", "mdx_compute_forces", "mdx_get_forces", "mdx_get_energies", "mdx_get_virial", "mdx_step",
     "mdx_synchronize", "mdx_get_list_stats", "mdx_pop_energy_frames", "mdx_pop_pull_records",
     "mdx_enable_kernel_timing", "mdx_get_kernel_timing", "mdx_debug_time_nonbonded", "mdx_debug_set", "mdx_debug_wave_times", "mdx_debug_stamps",
+    "mdx_dd_load", "mdx_dd_pack", "mdx_dd_unpack", "mdx_dd_step_begin", "mdx_dd_wait_spread", "mdx_dd_step_end", "mdx_dd_grid",
+    "mdx_dd_stream_sync", "mdx_dd_state_pointers",
     "mdx_debug_time_stage", "mdx_set_step", "mdx_generate_velocities", "mdx_constrain_start", "mdx_minimize",
     "mdx_frame_ring", "mdx_capture_frame", "mdx_frame_wait",
 ]
@@ -90,6 +92,13 @@ def load_library(path: str | None = None):
     L.mdx_debug_time_nonbonded.argtypes = [vp, c_int, c_int, dp]
     L.mdx_debug_set.argtypes = [vp, c_int, c_int]
     L.mdx_debug_wave_times.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong), c_int, ctypes.POINTER(c_int)]
+    L.mdx_dd_load.argtypes = [vp, c_int, c_int, vp, vp, c_int, c_d, c_d]
+    L.mdx_dd_pack.argtypes = [vp, c_int, vp, vp]
+    L.mdx_dd_unpack.argtypes = [vp, c_int, c_int, vp]
+    L.mdx_dd_step_begin.argtypes = [vp]; L.mdx_dd_wait_spread.argtypes = [vp]; L.mdx_dd_step_end.argtypes = [vp]
+    L.mdx_dd_grid.argtypes = [vp, ctypes.POINTER(vp), llp]
+    L.mdx_dd_stream_sync.argtypes = [vp]
+    L.mdx_dd_state_pointers.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
     L.mdx_debug_stamps.argtypes = [vp, c_int, ctypes.POINTER(ctypes.c_longlong)]
     L.mdx_debug_time_stage.argtypes = [vp, c_int, c_int, dp]
     L.mdx_set_step.argtypes = [vp, ctypes.c_longlong]
@@ -478,6 +487,39 @@ class Engine:
         buf = np.zeros((4096, 8), dtype=np.int64); nw = ctypes.c_int(0)
         self._call("mdx_debug_wave_times", buf.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), 4096, ctypes.byref(nw))
         return buf[:nw.value]
+
+    # ------------------------------------------------------------------ domain decomposition (device pointers as ints)
+    def dd_load(self, n_home, n_total, x4_ptr, v4_ptr, n_settle, ndf, density):
+        self._call("mdx_dd_load", int(n_home), int(n_total), ctypes.c_void_p(x4_ptr), ctypes.c_void_p(v4_ptr), int(n_settle),
+                   float(ndf), float(density))
+
+    def dd_pack(self, n, idx_ptr, out_ptr):
+        self._call("mdx_dd_pack", int(n), ctypes.c_void_p(idx_ptr), ctypes.c_void_p(out_ptr))
+
+    def dd_unpack(self, first, n, in_ptr):
+        self._call("mdx_dd_unpack", int(first), int(n), ctypes.c_void_p(in_ptr))
+
+    def dd_step_begin(self):
+        self._call("mdx_dd_step_begin")
+
+    def dd_wait_spread(self):
+        self._call("mdx_dd_wait_spread")
+
+    def dd_step_end(self):
+        self._call("mdx_dd_step_end")
+
+    def dd_stream_sync(self):
+        self._call("mdx_dd_stream_sync")
+
+    def dd_grid(self):
+        p = ctypes.c_void_p(0); n = ctypes.c_longlong(0)
+        self._call("mdx_dd_grid", ctypes.byref(p), ctypes.byref(n))
+        return p.value, n.value
+
+    def dd_state_pointers(self):
+        x = ctypes.c_void_p(0); v = ctypes.c_void_p(0)
+        self._call("mdx_dd_state_pointers", ctypes.byref(x), ctypes.byref(v))
+        return x.value, v.value
 
     def debug_stamps(self, reset=False):
         buf = np.zeros((2, 24), dtype=np.int64)
