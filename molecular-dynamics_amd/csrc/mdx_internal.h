@@ -166,6 +166,8 @@ struct mdx_system {
     // PME
     int K[3] = {0, 0, 0};
     float *grid = nullptr; float2 *cgrid = nullptr;
+    float *phi = nullptr;         // potential grid written by the own transform's last pass (the charge grid stays zeroed)
+    bool grid_clean = false;      // the charge grid is known to hold zeros
     float *bmod[3] = {nullptr, nullptr, nullptr};
     hipfftHandle plan_r2c = 0, plan_c2r = 0;
     float2 *fftW[3] = {nullptr, nullptr, nullptr};   // twiddle tables exp(-2 pi i j / K) of the own transform

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_pme_solve(float2 *__restrict__ cgrid, c
 // influence function + z inverse in one kernel, y inverse, x inverse (half-complex to real).
 // Unnormalised in both directions, layout of cgrid (K2, K1, K0/2+1) as hipFFT's R2C plan.
 struct FftArgs {
-    const float *grid_in; float *grid_out; float2 *cgrid;
+    float *grid_in; float *grid_out; float2 *cgrid;   // x forward reads grid_in and leaves it zeroed for the next spreading
     const float2 *W;            // exp(-2 pi i j / N), j < N, of the transformed dimension
     int K0, K1, K2, K0c;
     int N, N1, N2;
@@ -289,7 +289,9 @@ __global__ __launch_bounds__(256) void k_pme_fft(FftArgs A)
         if (MODE == 0) {
             for (int idx = threadIdx.x; idx < nl * N; idx += blockDim.x) {
                 const int l = idx / N, n = idx - l * N;
-                a[l * stride + n] = make_float2(L0 + l < nlines ? A.grid_in[(size_t)(L0 + l) * N + n] : 0.0f, 0.0f);
+                float q = 0.0f;
+                if (L0 + l < nlines) { q = A.grid_in[(size_t)(L0 + l) * N + n]; A.grid_in[(size_t)(L0 + l) * N + n] = 0.0f; }
+                a[l * stride + n] = make_float2(q, 0.0f);
             }
         } else {
             for (int idx = threadIdx.x; idx < nl * K0c; idx += blockDim.x) {
@@ -459,6 +461,8 @@ int mdx_pme_init(mdx_system *s)
     const size_t nr = (size_t)s->K[0] * s->K[1] * s->K[2];
     const size_t ncx = (size_t)s->K[2] * s->K[1] * (s->K[0] / 2 + 1);
     MDX_CHECK(s, hipMalloc(&s->grid, sizeof(float) * nr));
+    MDX_CHECK(s, hipMalloc(&s->phi, sizeof(float) * nr));
+    s->grid_clean = false;
     MDX_CHECK(s, hipMalloc(&s->cgrid, sizeof(float2) * ncx));
     for (int d = 0; d < 3; d++) {
         std::vector<float> bm;
@@ -489,6 +493,7 @@ int mdx_pme_init(mdx_system *s)
 void mdx_pme_free(mdx_system *s)
 {
     if (s->grid) { (void)hipFree(s->grid); s->grid = nullptr; }
+    if (s->phi) { (void)hipFree(s->phi); s->phi = nullptr; }
     if (s->cgrid) { (void)hipFree(s->cgrid); s->cgrid = nullptr; }
     for (int d = 0; d < 3; d++) if (s->bmod[d]) { (void)hipFree(s->bmod[d]); s->bmod[d] = nullptr; }
     for (int d = 0; d < 3; d++) if (s->fftW[d]) { (void)hipFree(s->fftW[d]); s->fftW[d] = nullptr; }
@@ -505,7 +510,9 @@ int mdx_launch_pme_spread(mdx_system *s, hipStream_t st, bool signal)
     if (!s->have_pme) return MDX_OK;
     const int K0 = s->K[0], K1 = s->K[1], K2 = s->K[2];
     const size_t nr = (size_t)K0 * K1 * K2;
-    MDX_CHECK(s, hipMemsetAsync(s->grid, 0, sizeof(float) * nr, st));
+    // the own transform's x pass leaves the charge grid zeroed; otherwise clear it here
+    if (!s->grid_clean) MDX_CHECK(s, hipMemsetAsync(s->grid, 0, sizeof(float) * nr, st));
+    s->grid_clean = false;
     {
         // window sizes from the column geometry (host copy of the box; a drift margin covers the rest)
         const double *bxd = s->h->boxd;
@@ -540,9 +547,10 @@ int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done)
     const int nb = (int)(((size_t)s->n * 16 + 255) / 256);
     if (!spread_done) { int rc = mdx_launch_pme_spread(s, s->st_pme, false); if (rc) return rc; }
     if (s->dbg & 256) { MDX_CHECK(s, hipGetLastError()); return MDX_OK; }       // diagnostic: spreading only
+    const float *potential = s->grid;       // the library path transforms in place
     if (s->own_fft && !(s->dbg & 512)) {
         FftArgs F;
-        F.grid_in = s->grid; F.grid_out = s->grid; F.cgrid = s->cgrid; F.K0 = K0; F.K1 = K1; F.K2 = K2; F.K0c = K0 / 2 + 1;
+        F.grid_in = s->grid; F.grid_out = s->phi; F.cgrid = s->cgrid; F.K0 = K0; F.K1 = K1; F.K2 = K2; F.K0c = K0 / 2 + 1;
         F.d = s->d; F.dw = s->d; F.bm0 = s->bmod[0]; F.bm1 = s->bmod[1]; F.bm2 = s->bmod[2]; F.beta = s->beta;
         auto lds = [](const FftArgs &f) { return sizeof(float2) * ((size_t)f.N + 2 * (size_t)f.nl * (f.N + 1)); };
         const int nchunk = (F.K0c + 7) / 8;
@@ -562,6 +570,8 @@ int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done)
         // x inverse
         F.N = K0; fft_split(K0, F.N1, F.N2); F.W = s->fftW[0]; F.nl = 16;
         hipLaunchKernelGGL((k_pme_fft<4, false>), dim3((K1 * K2 + F.nl - 1) / F.nl), dim3(256), lds(F), s->st_pme, F);
+        s->grid_clean = true;
+        potential = s->phi;
     } else {
     if (hipfftExecR2C(s->plan_r2c, s->grid, (hipfftComplex *)s->cgrid) != HIPFFT_SUCCESS) { s->err = "hipfftExecR2C failed"; return MDX_ERR_HIP; }
     const int nbs = (int)((ncx + 255) / 256);
@@ -573,7 +583,7 @@ int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done)
     }
     // the completion signal of the last kernel of the chain is the event the main stream waits for
     hipExtLaunchKernelGGL(k_pme_gather, dim3(nb), dim3(256), 0, s->st_pme, nullptr, s->ev_pme, 0, s->n, (const float4 *)s->x,
-                          (const DevState *)s->d, K0, K1, K2, (const float *)s->grid, s->f_pme);
+                          (const DevState *)s->d, K0, K1, K2, potential, s->f_pme);
     s->pme_signalled = true;
     MDX_CHECK(s, hipGetLastError());
     return MDX_OK;

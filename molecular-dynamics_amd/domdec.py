@@ -167,6 +167,56 @@ class Transport:
             dst.copy_(buf)
 
 
+class ThreadTransport:
+    """The same collectives between `world` domains that live in one process, one thread each (rehearsal and tests
+    on a single GPU: processes that share a GPU are time-sliced far more coarsely than a step lasts, threads of one
+    process are not). Create one `ThreadTransport.Hub(world)` and hand `hub.port(rank)` to each thread's domain."""
+
+    class Hub:
+        def __init__(self, world: int):
+            import threading
+            self.world = world
+            self.barrier = threading.Barrier(world)
+            self.slots = [None] * world
+
+        def port(self, rank: int):
+            return ThreadTransport(self, rank)
+
+    def __init__(self, hub, rank: int):
+        self.hub, self.rank, self.world, self.staged, self.group = hub, rank, hub.world, False, None
+
+    def _publish(self, obj):
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        self.hub.slots[self.rank] = obj
+        self.hub.barrier.wait()
+
+    def _done(self):
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        self.hub.barrier.wait()
+
+    def all_gather(self, t):
+        self._publish(t)
+        out = [s.clone() for s in self.hub.slots]
+        self._done()
+        return out
+
+    def all_reduce_sum_(self, t):
+        self._publish(t.clone())
+        total = torch.stack(list(self.hub.slots)).sum(0)
+        self._done()
+        t.copy_(total)
+        return t
+
+    def exchange(self, send, recv):
+        self._publish(send)
+        for r in range(self.world):
+            if r != self.rank and recv[r].numel():
+                recv[r].copy_(self.hub.slots[r][self.rank])
+        self._done()
+
+
 class _DevArray:
     """Wraps a raw device pointer for torch.as_tensor (CUDA array interface)."""
 
@@ -199,9 +249,9 @@ class DecomposedWater:
     def __init__(self, sysm: MDSystem, device: int = 0, rc: float = 1.0, dt: float = 0.002, nstlist: int = 20,
                  ref_t: float | None = 300.0, tau_t: float = 0.1, nsttcouple: int = 10, fourierspacing: float = 0.16,
                  rlist: float | None = None, seed: int = 1, group=None, dims=None, nstcalcenergy: int = 0,
-                 shared_device: bool = False):
+                 shared_device: bool = False, transport=None):
         from . import engine as eng
-        self.tr = Transport(group)
+        self.tr = transport if transport is not None else Transport(group)
         self.rank, self.world = self.tr.rank, self.tr.world
         self.dims = tuple(dims) if dims is not None else rank_grid(self.world)
         assert self.dims[0] * self.dims[1] * self.dims[2] == self.world

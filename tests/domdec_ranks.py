@@ -1,62 +1,63 @@
 #!/usr/bin/env python3
-"""Helper of test_gpu_domdec.py (also runnable by hand on a GPU box): `world` ranks share cuda:0 and talk through
-gloo; runs the decomposed water box and the single-handle run of the same box and prints one JSON line with
+"""Helper of test_gpu_domdec.py (also runnable by hand on a GPU box): `world` domains on cuda:0, one thread each in
+this one process (domdec.ThreadTransport; the torch.distributed transport is exercised on CPU by
+test_domdec_partition.py). Runs the decomposed water box and the single-handle run of the same box and prints one
+JSON line with
  - force parity: one step from rest (v = 0), so the new velocities are dt * f / m plus the constraint correction:
    relative RMS difference of the velocities between the two runs;
  - trajectory agreement after `steps` steps (pair-list lifetime 10: the partition is renewed on the way).
 python tests/domdec_ranks.py [world] [steps] [box d]"""
-import json, os, sys, time
+import json, os, sys, threading
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
-import torch.distributed as dist, torch.multiprocessing as mp
 
 
-def run(rank, world, steps, d, out, port):
-    import faulthandler; faulthandler.dump_traceback_later(170, exit=True)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def decomposed(world, nst, rest, d):
     import mdx
     from mdx import synth, domdec
-    res = {}
-    for label, nst, rest in (("rest", 1, True), ("traj", steps, False)):
-        s = synth.water_box(d=d)
-        if rest:
-            s.v = np.zeros_like(s.v)
-        dd = domdec.DecomposedWater(s, device=0, rc=1.0, dt=0.002, nstlist=10, ref_t=None, rlist=1.1, shared_device=True)
-        info = dict(dims=dd.dims, home=dd.n_home, halo=dd.n_halo, cap=dd.cap)
-        dd.step(nst); dd.synchronize()
-        x, v = dd.gather_state()
-        if rank == 0:
-            np.save(out + "_" + label + ".npy", np.stack([x, v]))
-            res[label] = info
-        dd.close()
-    if rank == 0:
-        json.dump(res, open(out + "_info.json", "w"))
-    dist.destroy_process_group()
+    hub = domdec.ThreadTransport.Hub(world)
+    out, err = {}, []
+
+    def rank_main(rank):
+        try:
+            s = synth.water_box(d=d)
+            if rest:
+                s.v = np.zeros_like(s.v)
+            dd = domdec.DecomposedWater(s, device=0, rc=1.0, dt=0.002, nstlist=10, ref_t=None, rlist=1.1, transport=hub.port(rank))
+            info = dict(dims=dd.dims, home=dd.n_home, halo=dd.n_halo, cap=dd.cap)
+            dd.step(nst); dd.synchronize()
+            x, v = dd.gather_state()
+            if rank == 0:
+                out.update(x=x, v=v, info=info)
+            dd.close()
+        except BaseException as e:      # a failing rank must not leave the others waiting at a barrier
+            err.append(e); hub.barrier.abort()
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in th: t.start()
+    for t in th: t.join()
+    if err:
+        raise err[0]
+    return out
 
 
 def main(world=2, steps=12, d=7.0):
-    out = "/tmp/mdx_dd_%d" % os.getpid()
-    mp.spawn(run, args=(world, steps, d, out, 29500 + os.getpid() % 400), nprocs=world, join=True)
+    import faulthandler; faulthandler.dump_traceback_later(int(os.environ.get("MDX_DD_LIMIT", "150")), exit=True)
     import mdx
     from mdx import synth, engine as eng
-    info = json.load(open(out + "_info.json"))
-    res = {"world": world, "steps": steps, "partition": info}
+    res = {"world": world, "steps": steps}
     for label, nst, rest in (("rest", 1, True), ("traj", steps, False)):
+        o = decomposed(world, nst, rest, d)
         s = synth.water_box(d=d)
         if rest:
             s.v = np.zeros_like(s.v)
         e = eng.Engine(s, rc=1.0, dt=0.002, nstlist=10, rlist=1.1, nstcalcenergy=0, nstcomm=0)
         e.step(nst); e.synchronize()
         xr, vr, _ = e.get_state(); e.close()
-        xd, vd = np.load(out + "_" + label + ".npy")
-        dx = xd - xr
+        dx = o["x"] - xr
         dx -= np.round(dx @ np.linalg.inv(s.box)) @ s.box
         res[label] = dict(dx_max=float(np.abs(dx).max()), dx_rms=float(np.sqrt((dx ** 2).mean())),
-                          dv_rel_rms=float(np.sqrt(((vd - vr) ** 2).mean() / (vr ** 2).mean())))
-    for f in ("_rest.npy", "_traj.npy", "_info.json"):
-        os.remove(out + f)
+                          dv_rel_rms=float(np.sqrt(((o["v"] - vr) ** 2).mean() / (vr ** 2).mean())), partition=o["info"])
     print(json.dumps(res), flush=True)
 
 
