@@ -287,6 +287,20 @@ def main():
                                    "sample": "%d leap-frog steps of the same %d-atom system with the float64 oracle "
                                              "(C cell-list nonbonded on %d OpenMP threads, numpy PME/bonded/SHAKE), %.1f s; "
                                              "own CPU restatement, not GROMACS" % (args.cpu_steps, s.natoms, threads, wall)}
+        # HBM-side kernels, each timed alone on its stream with HIP events after the run (the state is scrap afterwards):
+        # algorithmic bytes per launch / time against the 8 TB/s HBM peak
+        try:
+            K = e.grid; k3 = 4.0 * K[0] * K[1] * K[2]; n = s.natoms; nw = len(s.settles)
+            sec = []
+            for stage, name, nbytes in ((6, "k_pme_spread_col (+ grid clear)", 16.0 * n + 2 * k3), (7, "k_pme_gather", k3 + 28.0 * n),
+                                        (4, "k_leapfrog + k_settle + k_lincs", 64.0 * n + 144.0 * nw), (5, "k_prepare", 16.0 * n + 28.0 * n)):
+                ms = e.debug_time_stage(stage, 50)
+                gbs = nbytes / (ms * 1e-3) / 1e9
+                sec.append({"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+                            "bytes_per_launch": nbytes, "avg_launch_ms": round(ms, 5)})
+            out["roofline_secondary"] = sec
+        except Exception as ex:      # diagnostics must not lose the bench line
+            out["roofline_secondary"] = "failed: %s" % ex
         print(json.dumps(out), flush=True)
     e.close()
     if use_dist:

@@ -228,7 +228,7 @@ int mdx_debug_set(mdx_system *sys, int key, int value);
 int mdx_debug_stamps(mdx_system *sys, int reset, long long *out48);
 int mdx_debug_wave_times(mdx_system *sys, long long *out, int max_waves, int *nwaves);
 /* Average time (ms) of `iters` back-to-back runs of one stage on its own stream: 1 pair search,
- * 2 PME chain, 3 bonded + exclusion kernels, 4 update + constraints, 5 prepare, 6 PME spread.
+ * 2 PME chain, 3 bonded + exclusion kernels, 4 update + constraints, 5 prepare, 6 PME spread, 7 PME gather.
  * The state is not meaningful afterwards (diagnostic only). */
 int mdx_debug_time_stage(mdx_system *sys, int stage, int iters, double *avg_ms);
 

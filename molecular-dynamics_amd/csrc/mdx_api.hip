@@ -117,7 +117,7 @@ extern "C" void mdx_destroy(mdx_system *s)
                      s->col_count, s->col_astart, s->col_scstart, s->col_atoms, s->atom_col, s->atom_slot, s->wrapped, s->cj, s->work, s->work_order, s->sc_nwork,
                      s->exclmask, s->shift_ijk, s->shiftvec, s->bond_ij, s->bond_p, s->angle_ijk, s->angle_p, s->dih_ijkl, s->dih_p,
                      s->pair_ij, s->pair_p, s->posres_idx, s->posres_ref, s->posres_k, s->settle_idx, s->cons_ij, s->cons_len,
-                     s->comp_start, s->d_tc, s->pull_idx[0], s->pull_idx[1], s->gtab, s->dd_q0, s->dd_invm0, s->dd_lj0, s->d };
+                     s->comp_start, s->d_tc, s->pull_idx[0], s->pull_idx[1], s->gtab, s->htab, s->dd_q0, s->dd_invm0, s->dd_lj0, s->d };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (s->h) (void)hipHostFree(s->h);
     if (s->ener_log) (void)hipHostFree(s->ener_log);
@@ -344,6 +344,19 @@ extern "C" int mdx_set_nonbonded(mdx_system *s, float rc, float rlist, float bet
         const double g0 = g(wmax * k / MDX_GTAB_N), g1 = g(wmax * (k + 1) / MDX_GTAB_N);
         tab[k] = make_float2((float)g0, (float)(g1 - g0));
     }
+    auto h = [](double w) {
+        const double c = 1.1283791670955126;
+        if (w < 0.05) return c * (1.0 + w * (-1.0 / 3.0 + w * (0.1 + w * (-1.0 / 42.0 + w * (1.0 / 216.0 - w / 1320.0)))));
+        const double z = sqrt(w);
+        return erf(z) / z;
+    };
+    std::vector<float4> tab4(MDX_GTAB_N);
+    for (int k = 0; k < MDX_GTAB_N; k++) {
+        const double h0 = h(wmax * k / MDX_GTAB_N), h1 = h(wmax * (k + 1) / MDX_GTAB_N);
+        tab4[k] = make_float4(tab[k].x, tab[k].y, (float)h0, (float)(h1 - h0));
+    }
+    if (!s->htab) MDX_CHECK(s, hipMalloc((void **)&s->htab, sizeof(float4) * MDX_GTAB_N));
+    MDX_CHECK(s, hipMemcpy(s->htab, tab4.data(), sizeof(float4) * MDX_GTAB_N, hipMemcpyHostToDevice));
     if (!s->gtab) MDX_CHECK(s, hipMalloc((void **)&s->gtab, sizeof(float2) * MDX_GTAB_N));
     MDX_CHECK(s, hipMemcpy(s->gtab, tab.data(), sizeof(float2) * MDX_GTAB_N, hipMemcpyHostToDevice));
     return MDX_OK;
@@ -821,23 +834,24 @@ extern "C" long long mdx_pop_pull_records(mdx_system *s, double *out, long long 
 
 // Diagnostic: average time of `iters` back-to-back runs of one stage of the step on its own
 // stream, measured with HIP events. stage 1 pair search, 2 PME chain, 3 bonded + exclusion
-// kernels, 4 update + constraints, 5 prepare, 6 PME spread only (dbg bits select ablations).
+// kernels, 4 update + constraints, 5 prepare, 6 PME spread only, 7 PME gather only (dbg bits select ablations).
 extern "C" int mdx_debug_time_stage(mdx_system *s, int stage, int iters, double *avg_ms)
 {
     (void)hipSetDevice(s->device);
     int rc = sync_and_check(s); if (rc) return rc;
     MDX_CHECK(s, hipDeviceSynchronize());
     hipStream_t st = s->stream;
-    if (stage == 2 || stage == 6) st = s->st_pme;
+    if (stage == 2 || stage == 6 || stage == 7) st = s->st_pme;
     if (stage == 3) st = s->st_bond;
     hipEvent_t a, b;
     MDX_CHECK(s, hipEventCreate(&a)); MDX_CHECK(s, hipEventCreate(&b));
     const int saved = s->dbg;
     if (stage == 6) s->dbg |= 256;
+    if (stage == 7) s->dbg |= 2048;
     auto run = [&]() -> int {
         switch (stage) {
         case 1: return mdx_search(s);
-        case 2: case 6: return mdx_launch_pme(s, false);
+        case 2: case 6: case 7: return mdx_launch_pme(s, false);
         case 3: return mdx_launch_bonded(s, false, MDX_F_BONDED | MDX_F_POSRES);
         case 4: { int r = mdx_launch_update(s, false, false, false); float4 *t = s->x; s->x = s->xp; s->xp = t; return r; }
         case 5: return mdx_launch_prepare(s);

@@ -32,6 +32,7 @@ struct NbArgs {
     int central;                 // index of the zero lattice shift
     int do_pairs, do_excl;       // evaluate listed pairs / the Ewald correction of excluded pairs
     int dbg;                     // diagnostic ablation bits (timing experiments only)
+    const float4 *htab;          // MDX_GTAB_N entries (g, step of g, h, step of h), h(w) = erf(z)/z
     const float2 *gtab;          // MDX_GTAB_N entries (g(w_k), g(w_k+1) - g(w_k)), w_k = beta^2 rc^2 k / MDX_GTAB_N
     float tab_scale;             // MDX_GTAB_N / rc^2
     int dyn_split;               // log2 of the parts a unit is cut into when handed out dynamically
@@ -76,7 +77,8 @@ __device__ __forceinline__ float mdx_pmecorr(float w)
 // load and broadcast with v_readlane, the j-atoms of entry e+1 are requested before entry e is
 // evaluated, two j-clusters share one 48-lane float atomic, and the force-only variant replaces
 // exp + erfc by the rational Ewald correction above.
-// ABL bits: 1, 2 remove arithmetic (timing experiments); 4 takes the Ewald correction g from the table `gtab` in LDS.
+// ABL bits: 1, 2 remove arithmetic (timing experiments); 4 takes the Ewald correction g from the table `gtab` in LDS;
+// 8 (energy kernel) takes g and h = erf(z)/z from a float4 table.
 template <bool ENERGY, bool TIMED = false, int ABL = 0>
 __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nullptr)
 {
@@ -211,7 +213,18 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                 float fs = t6 * fmaf(12.0f, s6, -6.0f);
                 const float qq = qi[c] * pj.w;
                 float erfc_br = 0.0f, e_ex = 0.0f;
-                if (ENERGY) {
+                if (ENERGY && (ABL & 8)) {
+                    // g and h(w) = erf(z)/z from one LDS table entry: erfc(beta r)/r = 1/r - beta h, no exponential
+                    const float t = r2 * A.tab_scale;
+                    const float4 te = ((const float4 *)gtab)[(unsigned)t & (MDX_GTAB_N - 1)];
+                    const float fr = __builtin_amdgcn_fractf(t);
+                    const float g = fmaf(fr, te.y, te.x), h = fmaf(fr, te.w, te.z);
+                    fs = fmaf(qq, rinv, fs) * rinv2;
+                    if (GENERAL && slot) fs = listed ? fs : 0.0f;
+                    fs = fmaf(-qq * beta3, g, fs);
+                    erfc_br = fmaf(-beta * h, r2 * rinv, 1.0f);        // erfc(beta r) = 1 - beta r h
+                    e_ex = -qq * beta * h;
+                } else if (ENERGY) {
                     const float br = beta * r2 * rinv;
                     const float ex2 = __builtin_amdgcn_exp2f(nb2l2e * r2);
                     erfc_br = ex2 * mdx_erfcx_poly(br);
@@ -361,6 +374,15 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __syncthreads();
     nb_body<false, false, 4>(A, (const float2 *)tab4);
 }
+// Energy/virial kernel with g and h tabulated (64 KB per CU): no exponential, no erfc polynomial.
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_evt(NbArgs A)
+{
+    __shared__ float4 tab4[MDX_GTAB_N];
+    const float4 *src = (const float4 *)A.htab;
+    for (int k = threadIdx.x; k < MDX_GTAB_N; k += 768) tab4[k] = src[k];
+    __syncthreads();
+    nb_body<true, false, 8>(A, (const float2 *)tab4);
+}
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3_abl1(NbArgs A) { nb_body<false, false, 1>(A); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3_abl2(NbArgs A) { nb_body<false, false, 2>(A); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3_timed(NbArgs A) { nb_body<false, true>(A); }
@@ -374,7 +396,7 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
     A.dbg = s->dbg;
     A.wave_t = s->nb_wave_t;
     A.dyn = s->nb_dyn; A.dyn_split = s->nb_dyn_split;
-    A.gtab = s->gtab; A.tab_scale = (float)MDX_GTAB_N / (s->rc * s->rc);
+    A.htab = s->htab; A.gtab = s->gtab; A.tab_scale = (float)MDX_GTAB_N / (s->rc * s->rc);
     A.do_pairs = (terms & MDX_F_NONBONDED) ? 1 : 0;
     A.do_excl = ((terms & MDX_F_EXCL) && s->beta > 0.0f) ? 1 : 0;
     if (!A.do_pairs && !A.do_excl) return MDX_OK;
@@ -402,6 +424,7 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
     void (*kern)(NbArgs) = k_nonbonded_f;
     dim3 grid(nblk), block(256);
     if (energy && wv == 2) kern = k_nonbonded_ev2;
+    else if (energy && wv == 3 && s->htab && !(s->dbg & 0x400000)) { kern = k_nonbonded_evt; grid = dim3(256); block = dim3(768); }
     else if (energy) kern = k_nonbonded_ev;
     else if (wv == 2) kern = k_nonbonded_f2;
     else if (wv == 3) {

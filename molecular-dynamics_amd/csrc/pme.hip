@@ -532,9 +532,13 @@ int mdx_launch_pme_spread(mdx_system *s, hipStream_t st, bool signal)
         A.delta = (float)delta; A.grid = s->grid; A.v_home = s->dd_on ? s->v : nullptr;
         if (getenv("MDX_PME_NOTILE")) { A.T0 = 4; A.T1 = 4; }
         const size_t lds = (size_t)A.ppc * A.T0 * A.T1 * 4 + (size_t)A.ppc * 8;
-        hipExtLaunchKernelGGL(k_pme_spread_col, dim3(s->ncx * s->ncy, nchunk), dim3(256), lds, st, nullptr, signal ? s->ev_spread : nullptr, 0, A, (const DevState *)s->d);
+        hipLaunchKernelGGL(k_pme_spread_col, dim3(s->ncx * s->ncy, nchunk), dim3(256), lds, st, A, (const DevState *)s->d);
         MDX_CHECK(s, hipGetLastError());
-        if (signal) MDX_CHECK(s, hipStreamWaitEvent(s->st_pme, s->ev_spread, 0));
+        if (signal) {
+            // a marker behind the kernel (a completion signal on the kernel itself holds the next kernel of this queue back by ~19 us)
+            MDX_CHECK(s, hipEventRecord(s->ev_spread, st));
+            MDX_CHECK(s, hipStreamWaitEvent(s->st_pme, s->ev_spread, 0));
+        }
     }
     return MDX_OK;
 }
@@ -545,6 +549,12 @@ int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done)
     const int K0 = s->K[0], K1 = s->K[1], K2 = s->K[2];
     const size_t ncx = (size_t)K2 * K1 * (K0 / 2 + 1);
     const int nb = (int)(((size_t)s->n * 16 + 255) / 256);
+    if (s->dbg & 2048) {       // diagnostic: the gather alone (stage timing)
+        hipLaunchKernelGGL(k_pme_gather, dim3(nb), dim3(256), 0, s->st_pme, s->n, (const float4 *)s->x, (const DevState *)s->d, K0, K1, K2,
+                           (const float *)(s->own_fft ? s->phi : s->grid), s->f_pme);
+        MDX_CHECK(s, hipGetLastError());
+        return MDX_OK;
+    }
     if (!spread_done) { int rc = mdx_launch_pme_spread(s, s->st_pme, false); if (rc) return rc; }
     if (s->dbg & 256) { MDX_CHECK(s, hipGetLastError()); return MDX_OK; }       // diagnostic: spreading only
     const float *potential = s->grid;       // the library path transforms in place

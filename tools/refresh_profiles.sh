@@ -7,3 +7,5 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpu
 cd $R
 tail -2 gpurun_out/pytest_gpu_v3.log; cat gpurun_out/bench_v4.json
 MDX_LIB=molecular-dynamics_amd/libmdx_ts.so timeout -k 10 300 python tools/step_stamps.py > gpurun_out/step_stamps_v4.txt 2>&1
+bash tools/nb_pmc.sh > gpurun_out/nb_pmc.log 2>&1
+bash tools/nb_sq.sh > gpurun_out/nb_sq_v4.txt 2>&1
