@@ -79,7 +79,9 @@ __device__ __forceinline__ float mdx_pmecorr(float w)
 // exp + erfc by the rational Ewald correction above.
 // ABL bits: 1, 2 remove arithmetic (timing experiments); 4 takes the Ewald correction g from the table `gtab` in LDS;
 // 8 (energy kernel) takes g and h = erf(z)/z from a float4 table.
-template <bool ENERGY, bool TIMED = false, int ABL = 0>
+// NI: i-clusters of the super-cluster held in registers at a time; NI = 4 walks the unit's entries twice (36 registers
+// fewer, j-atoms loaded and j-forces reduced twice), so that waves of other kernels fit beside the energy kernel.
+template <bool ENERGY, bool TIMED = false, int ABL = 0, int NI = 8>
 __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nullptr)
 {
     MDX_STAMP(A.dw, ENERGY ? 2 : 1);
@@ -144,11 +146,14 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
         const float4 S = A.shiftvec[shift_idx];
         NbEntry myent; myent.cj = 0; myent.mask = 0;
         if (lane < count) myent = A.cj[e0 + lane];
-        float xi[8], yi[8], zi[8], qi[8], hsi[8], sei[8];
-        float fix[8], fiy[8], fiz[8];
+#pragma unroll 1
+        for (int half = 0; half < 8 / NI; half++) {
+        const int c0 = half * NI;
+        float xi[NI], yi[NI], zi[NI], qi[NI], hsi[NI], sei[NI];
+        float fix[NI], fiy[NI], fiz[NI];
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const int ia = (sci * 8 + c) * 8 + ti;
+        for (int c = 0; c < NI; c++) {
+            const int ia = (sci * 8 + c0 + c) * 8 + ti;
             const float4 p = A.xq_s[ia];
             const float2 l = A.lj_s[ia];
             xi[c] = p.x - S.x; yi[c] = p.y - S.y; zi[c] = p.z - S.z;
@@ -178,7 +183,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                 ex_n = 0xFFu;
                 if (mk_n >> 8) ex_n = A.exclmask[(size_t)(mk_n >> 8) * 64 + lane];
             }
-            const unsigned imask = mk & 0xFFu;
+            const unsigned imask = ((mk & 0xFFu) >> c0) & ((1u << NI) - 1u);
             const unsigned slot = mk >> 8;
             // `live` bit c: this lane's pair with i-cluster c is evaluated at all. In the tile of a
             // cluster with itself only tj > ti is (each pair once, no self pair); listed pairs need
@@ -186,6 +191,8 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
             unsigned live = do_pairs ? ex : 0u;
             if (do_excl) live |= ~ex & 0xFFu;
             if (is_central && (cj >> 3) == sci && tj <= ti) live &= ~(1u << (cj & 7));
+            live >>= c0;
+            const unsigned exh = ex >> c0;
             float fjx = 0.0f, fjy = 0.0f, fjz = 0.0f;
             bool did = false;           // wave-uniform: some tile of this entry had a pair inside the cutoff
             // One 8x8 tile: i-cluster c against the j-cluster. GENERAL tiles look at the exclusion and
@@ -202,7 +209,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                 // cutoff right now costs only the distance test (wave-uniform skip)
                 if (__builtin_amdgcn_ballot_w64(within) == 0ull) return;
                 did = true;
-                const bool listed = GENERAL ? (((ex >> c) & 1u) != 0u) : true;   // false: excluded pair, Ewald correction only
+                const bool listed = GENERAL ? (((exh >> c) & 1u) != 0u) : true;   // false: excluded pair, Ewald correction only
                 const float rinv = __frsqrt_rn(r2);
                 const float rinv2 = rinv * rinv;
                 const float sg = hsi[c] + lj.x;
@@ -274,11 +281,11 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
             const bool general = slot != 0u || !do_pairs || (is_central && (cj >> 3) == sci);    // wave-uniform
             if (!general) {
 #pragma unroll
-                for (int c = 0; c < 8; c++)
+                for (int c = 0; c < NI; c++)
                     if (imask & (1u << c)) tile(std::false_type{}, c);
             } else {
 #pragma unroll
-                for (int c = 0; c < 8; c++)
+                for (int c = 0; c < NI; c++)
                     if (imask & (1u << c)) tile(std::true_type{}, c);
             }
             // an entry none of whose tiles had a pair inside the cutoff has no j-force to reduce or add
@@ -302,15 +309,16 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
             }
         }
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
+        for (int c = 0; c < NI; c++) {
             float ax = fix[c], ay = fiy[c], az = fiz[c];
             ax += dpp_row_ror8(ax); ay += dpp_row_ror8(ay); az += dpp_row_ror8(az);
             ax += __shfl_xor(ax, 16, 64); ay += __shfl_xor(ay, 16, 64); az += __shfl_xor(az, 16, 64);
             ax += __shfl_xor(ax, 32, 64); ay += __shfl_xor(ay, 32, 64); az += __shfl_xor(az, 32, 64);
             if (tj < 3 && !(A.dbg & 0x40000)) {
                 const float val = (tj == 0) ? ax : ((tj == 1) ? ay : az);
-                atomicAdd(&A.f_s[3 * ((sci * 8 + c) * 8 + ti) + tj], val);
+                atomicAdd(&A.f_s[3 * ((sci * 8 + c0 + c) * 8 + ti) + tj], val);
             }
+        }
         }
         }
         unit = unit_n; part = part_n; w = w_n;
@@ -383,6 +391,15 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __syncthreads();
     nb_body<true, false, 8>(A, (const float2 *)tab4);
 }
+// The same holding four i-clusters at a time: fits beside the kernels of the PME and bonded streams.
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_evt4(NbArgs A)
+{
+    __shared__ float4 tab4[MDX_GTAB_N];
+    const float4 *src = (const float4 *)A.htab;
+    for (int k = threadIdx.x; k < MDX_GTAB_N; k += 768) tab4[k] = src[k];
+    __syncthreads();
+    nb_body<true, false, 8, 4>(A, (const float2 *)tab4);
+}
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3_abl1(NbArgs A) { nb_body<false, false, 1>(A); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3_abl2(NbArgs A) { nb_body<false, false, 2>(A); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3_timed(NbArgs A) { nb_body<false, true>(A); }
@@ -424,7 +441,7 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
     void (*kern)(NbArgs) = k_nonbonded_f;
     dim3 grid(nblk), block(256);
     if (energy && wv == 2) kern = k_nonbonded_ev2;
-    else if (energy && wv == 3 && s->htab && !(s->dbg & 0x400000)) { kern = k_nonbonded_evt; grid = dim3(256); block = dim3(768); }
+    else if (energy && wv == 3 && s->htab && !(s->dbg & 0x400000)) { kern = (s->dbg & 0x1000000) ? k_nonbonded_evt : k_nonbonded_evt4; grid = dim3(256); block = dim3(768); }
     else if (energy) kern = k_nonbonded_ev;
     else if (wv == 2) kern = k_nonbonded_f2;
     else if (wv == 3) {

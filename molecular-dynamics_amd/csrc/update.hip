@@ -48,12 +48,10 @@ __global__ __launch_bounds__(256) void k_leapfrog(int n, const float4 *__restric
 // One thread per molecule; also corrects velocities and, on virial steps, accumulates the
 // constraint virial -1/2 sum r_old (x) G with G = m dx / dt^2.
 template <bool VIRIAL>
-__global__ __launch_bounds__(256) void k_settle(int nw, const int4 *__restrict__ idx, const float4 *__restrict__ x,
-                                                float4 *__restrict__ xp, float4 *__restrict__ v, float doh, float dhh,
-                                                float inv_dt, DevState *dw)
+__device__ __forceinline__ void d_settle(const int t, int nw, const int4 *__restrict__ idx, const float4 *__restrict__ x,
+                                         float4 *__restrict__ xp, float4 *__restrict__ v, float doh, float dhh,
+                                         float inv_dt, DevState *dw)
 {
-    MDX_STAMP(dw, 12);
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
     float v9[9] = { 0 };
     if (t < nw) {
         const int4 a = idx[t];
@@ -132,12 +130,10 @@ __global__ __launch_bounds__(256) void k_settle(int nw, const int4 *__restrict__
 // constant bounds so that the per-component arrays live in registers; the rest use MAXK = 16.
 #define LINCS_FOR(k) _Pragma("unroll") for (int k = 0; k < (MAXK <= 4 ? MAXK : K); k++) if (MAXK > 4 || k < K)
 template <bool VIRIAL, int MAXK>
-__global__ __launch_bounds__(128) void k_lincs(int comp0, int ncomp, const int *__restrict__ comp_start, const int2 *__restrict__ cij,
-                                               const float *__restrict__ clen, const float4 *__restrict__ x, float4 *__restrict__ xp,
-                                               float4 *__restrict__ v, int order, int niter, float inv_dt, DevState *dw)
+__device__ __forceinline__ void d_lincs(const int t, int comp0, int ncomp, const int *__restrict__ comp_start, const int2 *__restrict__ cij,
+                                        const float *__restrict__ clen, const float4 *__restrict__ x, float4 *__restrict__ xp,
+                                        float4 *__restrict__ v, int order, int niter, float inv_dt, DevState *dw)
 {
-    MDX_STAMP(dw, 13);
-    const int t = comp0 + blockIdx.x * blockDim.x + threadIdx.x;
     float v9[9] = { 0 };
     if (t < comp0 + ncomp) {
         const int c0 = comp_start[t];
@@ -218,6 +214,45 @@ __global__ __launch_bounds__(128) void k_lincs(int comp0, int ncomp, const int *
             if (threadIdx.x == 0) atomicAdd(&MDX_VIR(dw, k), -0.5 * r);
         }
     }
+}
+
+template <bool VIRIAL>
+__global__ __launch_bounds__(256) void k_settle(int nw, const int4 *__restrict__ idx, const float4 *__restrict__ x,
+                                                float4 *__restrict__ xp, float4 *__restrict__ v, float doh, float dhh,
+                                                float inv_dt, DevState *dw)
+{
+    MDX_STAMP(dw, 12);
+    d_settle<VIRIAL>(blockIdx.x * blockDim.x + threadIdx.x, nw, idx, x, xp, v, doh, dhh, inv_dt, dw);
+}
+
+template <bool VIRIAL, int MAXK>
+__global__ __launch_bounds__(128) void k_lincs(int comp0, int ncomp, const int *__restrict__ comp_start, const int2 *__restrict__ cij,
+                                               const float *__restrict__ clen, const float4 *__restrict__ x, float4 *__restrict__ xp,
+                                               float4 *__restrict__ v, int order, int niter, float inv_dt, DevState *dw)
+{
+    MDX_STAMP(dw, 13);
+    d_lincs<VIRIAL, MAXK>(comp0 + blockIdx.x * blockDim.x + threadIdx.x, comp0, ncomp, comp_start, cij, clen, x, xp, v, order, niter, inv_dt, dw);
+}
+
+// SETTLE and both LINCS instantiations in one launch (they touch disjoint atoms): consecutive ranges of 128-thread
+// workgroups. The update sits on the critical path of every step and each launch costs more than its arithmetic.
+struct ConstrainArgs {
+    int nbw, nb4;               // workgroups of the settle range, of the small-component range (the rest: large components)
+    int nw; const int4 *settle_idx; float doh, dhh;
+    int ncomp_small, ncomp; const int *comp_start; const int2 *cij; const float *clen; int order, niter;
+    const float4 *x; float4 *xp; float4 *v; float inv_dt; DevState *dw;
+};
+template <bool VIRIAL>
+__global__ __launch_bounds__(128) void k_constrain(ConstrainArgs A)
+{
+    MDX_STAMP(A.dw, 12);
+    const int b = blockIdx.x;
+    if (b < A.nbw) d_settle<VIRIAL>(b * 128 + threadIdx.x, A.nw, A.settle_idx, A.x, A.xp, A.v, A.doh, A.dhh, A.inv_dt, A.dw);
+    else if (b < A.nbw + A.nb4)
+        d_lincs<VIRIAL, 4>((b - A.nbw) * 128 + threadIdx.x, 0, A.ncomp_small, A.comp_start, A.cij, A.clen, A.x, A.xp, A.v, A.order, A.niter, A.inv_dt, A.dw);
+    else
+        d_lincs<VIRIAL, MDX_LINCS_MAXK>(A.ncomp_small + (b - A.nbw - A.nb4) * 128 + threadIdx.x, A.ncomp_small, A.ncomp - A.ncomp_small,
+                                        A.comp_start, A.cij, A.clen, A.x, A.xp, A.v, A.order, A.niter, A.inv_dt, A.dw);
 }
 
 // Half-step kinetic energy per T-coupling group (+ tensor) from the current velocities.
@@ -453,6 +488,18 @@ int mdx_launch_update(mdx_system *s, bool do_tc, bool do_pr, bool virial)
 // (inv_dt = 0 leaves them alone, inv_dt = -1/dt serves the start-up velocity projection).
 int mdx_launch_constrain(mdx_system *s, float inv_dt, bool virial, int lincs_iter)
 {
+    if (s->nsettle > 0 && s->ncomp > 0) {
+        ConstrainArgs A;
+        A.nbw = (s->nsettle + 127) / 128; A.nb4 = (s->ncomp_small + 127) / 128;
+        const int nb16 = (s->ncomp - s->ncomp_small + 127) / 128;
+        A.nw = s->nsettle; A.settle_idx = s->settle_idx; A.doh = s->settle_doh; A.dhh = s->settle_dhh;
+        A.ncomp_small = s->ncomp_small; A.ncomp = s->ncomp; A.comp_start = s->comp_start; A.cij = s->cons_ij; A.clen = s->cons_len;
+        A.order = s->lincs_order; A.niter = lincs_iter; A.x = s->x; A.xp = s->xp; A.v = s->v; A.inv_dt = inv_dt; A.dw = s->d;
+        if (virial) hipLaunchKernelGGL(k_constrain<true>, dim3(A.nbw + A.nb4 + nb16), dim3(128), 0, s->stream, A);
+        else hipLaunchKernelGGL(k_constrain<false>, dim3(A.nbw + A.nb4 + nb16), dim3(128), 0, s->stream, A);
+        MDX_CHECK(s, hipGetLastError());
+        return MDX_OK;
+    }
     if (s->nsettle > 0) {
         const int nbw = (s->nsettle + 255) / 256;
         if (virial) hipLaunchKernelGGL(k_settle<true>, dim3(nbw), dim3(256), 0, s->stream, s->nsettle, s->settle_idx, s->x, s->xp, s->v, s->settle_doh, s->settle_dhh, inv_dt, s->d);
