@@ -274,6 +274,118 @@ __device__ __forceinline__ void dft_lines(float2 *a, float2 *b, const float2 *W,
     __syncthreads();
 }
 
+// The same two passes for lines laid out with strides: element n of line l at a[l * ls + n * es]. With LINE_FAST
+// consecutive threads take consecutive lines (for es > 1, where consecutive n would collide on LDS banks).
+template <bool LINE_FAST>
+__device__ __forceinline__ void dft_strided(float2 *a, float2 *b, const float2 *W, int nl, int N, int N1, int N2, bool inverse, int ls, int es)
+{
+    const float sgn = inverse ? -1.0f : 1.0f;
+    for (int idx = threadIdx.x; idx < nl * N; idx += blockDim.x) {
+        const int line = LINE_FAST ? idx % nl : idx / N, r = LINE_FAST ? idx / nl : idx - (idx / N) * N;
+        const int k1 = r / N2, n2 = r - k1 * N2;
+        const float2 *x = a + line * ls + n2 * es;
+        float re = 0.0f, im = 0.0f;
+        int j = 0; const int step = k1 * N2;
+        for (int n1 = 0; n1 < N1; n1++) {
+            const float2 w = W[j]; const float2 v = x[n1 * N2 * es];
+            const float wy = sgn * w.y;
+            re = fmaf(v.x, w.x, fmaf(-v.y, wy, re));
+            im = fmaf(v.x, wy, fmaf(v.y, w.x, im));
+            j += step; if (j >= N) j -= N;
+        }
+        const float2 t = W[n2 * k1]; const float ty = sgn * t.y;
+        b[line * ls + r * es] = make_float2(re * t.x - im * ty, re * ty + im * t.x);
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < nl * N; idx += blockDim.x) {
+        const int line = LINE_FAST ? idx % nl : idx / N, r = LINE_FAST ? idx / nl : idx - (idx / N) * N;
+        const int k1 = r / N2, k2 = r - k1 * N2;
+        const float2 *x = b + line * ls + k1 * N2 * es;
+        float re = 0.0f, im = 0.0f;
+        int j = 0; const int step = k2 * N1;
+        for (int n2 = 0; n2 < N2; n2++) {
+            const float2 w = W[j]; const float2 v = x[n2 * es];
+            const float wy = sgn * w.y;
+            re = fmaf(v.x, w.x, fmaf(-v.y, wy, re));
+            im = fmaf(v.x, wy, fmaf(v.y, w.x, im));
+            j += step; if (j >= N) j -= N;
+        }
+        a[line * ls + (k1 + N1 * k2) * es] = make_float2(re, im);
+    }
+    __syncthreads();
+}
+
+// x and y passes of one grid plane in one workgroup (planes of up to ~100 KB of LDS): forward reads the real plane in
+// batches of XB lines (leaving it zeroed), keeps the half-complex plane in LDS for the y pass and stores it; inverse
+// goes the other way and writes the real potential plane. Two launches and two passes through memory less per direction.
+#define MDX_FFT_XB 16
+struct Fft2Args {
+    float *grid_in; float *grid_out; float2 *cgrid;
+    const float2 *W0, *W1;
+    int K0, K1, K0c;
+    int N01, N02, N11, N12;     // factor pairs of K0 and K1
+};
+template <bool INVERSE>
+__global__ __launch_bounds__(512) void k_pme_fft2d(Fft2Args A, const DevState *d)
+{
+    MDX_STAMP(d, INVERSE ? 7 : 4);
+    extern __shared__ float2 fsm[];
+    const int K0 = A.K0, K1 = A.K1, K0c = A.K0c, ps = K0c + 1, xs = K0 + 1;
+    float2 *W0 = fsm, *W1 = W0 + K0, *P = W1 + K1, *Q = P + K1 * ps, *xa = Q + K1 * ps, *xb = xa + MDX_FFT_XB * xs;
+    for (int j = threadIdx.x; j < K0; j += blockDim.x) W0[j] = A.W0[j];
+    for (int j = threadIdx.x; j < K1; j += blockDim.x) W1[j] = A.W1[j];
+    const size_t plane = blockIdx.x;
+    float *rin = A.grid_in + plane * K1 * K0;
+    float *rout = A.grid_out + plane * K1 * K0;
+    float2 *cp = A.cgrid + plane * K1 * K0c;
+    if (!INVERSE) {
+        for (int l0 = 0; l0 < K1; l0 += MDX_FFT_XB) {
+            const int nl = min(MDX_FFT_XB, K1 - l0);
+            for (int idx = threadIdx.x; idx < nl * K0; idx += blockDim.x) {
+                const int l = idx / K0, n = idx - l * K0;
+                const float q = rin[(l0 + l) * K0 + n];
+                rin[(l0 + l) * K0 + n] = 0.0f;
+                xa[l * xs + n] = make_float2(q, 0.0f);
+            }
+            __syncthreads();
+            dft_strided<false>(xa, xb, W0, nl, K0, A.N01, A.N02, false, xs, 1);
+            for (int idx = threadIdx.x; idx < nl * K0c; idx += blockDim.x) {
+                const int l = idx / K0c, k = idx - l * K0c;
+                P[(l0 + l) * ps + k] = xa[l * xs + k];
+            }
+            __syncthreads();
+        }
+        dft_strided<true>(P, Q, W1, K0c, K1, A.N11, A.N12, false, 1, ps);
+        for (int idx = threadIdx.x; idx < K1 * K0c; idx += blockDim.x) {
+            const int y = idx / K0c, k = idx - y * K0c;
+            cp[idx] = P[y * ps + k];
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < K1 * K0c; idx += blockDim.x) {
+            const int y = idx / K0c, k = idx - y * K0c;
+            P[y * ps + k] = cp[idx];
+        }
+        __syncthreads();
+        dft_strided<true>(P, Q, W1, K0c, K1, A.N11, A.N12, true, 1, ps);
+        for (int l0 = 0; l0 < K1; l0 += MDX_FFT_XB) {
+            const int nl = min(MDX_FFT_XB, K1 - l0);
+            for (int idx = threadIdx.x; idx < nl * K0c; idx += blockDim.x) {
+                const int l = idx / K0c, k = idx - l * K0c;
+                const float2 v = P[(l0 + l) * ps + k];
+                xa[l * xs + k] = v;
+                if (k > 0 && K0 - k >= K0c) xa[l * xs + K0 - k] = make_float2(v.x, -v.y);
+            }
+            __syncthreads();
+            dft_strided<false>(xa, xb, W0, nl, K0, A.N01, A.N02, true, xs, 1);
+            for (int idx = threadIdx.x; idx < nl * K0; idx += blockDim.x) {
+                const int l = idx / K0, n = idx - l * K0;
+                rout[(l0 + l) * K0 + n] = xa[l * xs + n].x;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // MODE 0: x forward (real lines -> half-complex), 4: x inverse; 1 / 3: y forward / inverse; 2: z forward, solve, z inverse
 template <int MODE, bool ENERGY>
 __global__ __launch_bounds__(256) void k_pme_fft(FftArgs A)
@@ -486,6 +598,9 @@ int mdx_pme_init(mdx_system *s)
         MDX_CHECK(s, hipMalloc((void **)&s->fftW[d], sizeof(float2) * s->K[d]));
         MDX_CHECK(s, hipMemcpy(s->fftW[d], w.data(), sizeof(float2) * s->K[d], hipMemcpyHostToDevice));
     }
+    // the plane kernels may ask for more than the default 64 KB of dynamic LDS
+    MDX_CHECK(s, hipFuncSetAttribute((const void *)k_pme_fft2d<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    MDX_CHECK(s, hipFuncSetAttribute((const void *)k_pme_fft2d<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     s->have_pme = true;
     return MDX_OK;
 }
@@ -564,22 +679,38 @@ int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done)
         F.d = s->d; F.dw = s->d; F.bm0 = s->bmod[0]; F.bm1 = s->bmod[1]; F.bm2 = s->bmod[2]; F.beta = s->beta;
         auto lds = [](const FftArgs &f) { return sizeof(float2) * ((size_t)f.N + 2 * (size_t)f.nl * (f.N + 1)); };
         const int nchunk = (F.K0c + 7) / 8;
+        Fft2Args G;
+        G.grid_in = s->grid; G.grid_out = s->phi; G.cgrid = s->cgrid; G.W0 = s->fftW[0]; G.W1 = s->fftW[1]; G.K0 = K0; G.K1 = K1; G.K0c = F.K0c;
+        fft_split(K0, G.N01, G.N02); fft_split(K1, G.N11, G.N12);
+        const size_t lds2 = sizeof(float2) * ((size_t)K0 + K1 + 2 * (size_t)K1 * (F.K0c + 1) + 2 * (size_t)MDX_FFT_XB * (K0 + 1));
+        // measured slower than the per-direction passes at 80x80x56 (one workgroup per plane: 56 workgroups, 35 us per
+        // launch beside the nonbonded kernel against 19 + 6 us): off unless asked for (mdx_debug_set key 2, bit 0x2000000)
+        const bool planes = lds2 <= 100 * 1024 && (s->dbg & 0x2000000);
+        if (planes) {
+            // x and y forward, one workgroup per plane
+            hipLaunchKernelGGL(k_pme_fft2d<false>, dim3(K2), dim3(512), lds2, s->st_pme, G, (const DevState *)s->d);
+        } else {
         // x forward
         F.N = K0; fft_split(K0, F.N1, F.N2); F.W = s->fftW[0]; F.nl = 16;
         hipLaunchKernelGGL((k_pme_fft<0, false>), dim3((K1 * K2 + F.nl - 1) / F.nl), dim3(256), lds(F), s->st_pme, F);
         // y forward
         F.N = K1; fft_split(K1, F.N1, F.N2); F.W = s->fftW[1]; F.nl = 8;
         hipLaunchKernelGGL((k_pme_fft<1, false>), dim3(K2 * nchunk), dim3(256), lds(F), s->st_pme, F);
+        }
         // z forward, influence function, z inverse
         F.N = K2; fft_split(K2, F.N1, F.N2); F.W = s->fftW[2]; F.nl = 8;
         if (energy) hipLaunchKernelGGL((k_pme_fft<2, true>), dim3(K1 * nchunk), dim3(256), lds(F), s->st_pme, F);
         else hipLaunchKernelGGL((k_pme_fft<2, false>), dim3(K1 * nchunk), dim3(256), lds(F), s->st_pme, F);
+        if (planes) {
+            hipLaunchKernelGGL(k_pme_fft2d<true>, dim3(K2), dim3(512), lds2, s->st_pme, G, (const DevState *)s->d);
+        } else {
         // y inverse
         F.N = K1; fft_split(K1, F.N1, F.N2); F.W = s->fftW[1]; F.nl = 8;
         hipLaunchKernelGGL((k_pme_fft<3, false>), dim3(K2 * nchunk), dim3(256), lds(F), s->st_pme, F);
         // x inverse
         F.N = K0; fft_split(K0, F.N1, F.N2); F.W = s->fftW[0]; F.nl = 16;
         hipLaunchKernelGGL((k_pme_fft<4, false>), dim3((K1 * K2 + F.nl - 1) / F.nl), dim3(256), lds(F), s->st_pme, F);
+        }
         s->grid_clean = true;
         potential = s->phi;
     } else {
