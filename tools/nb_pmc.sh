@@ -8,6 +8,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   python3 $R/tools/pmc_summary.py $f k_nonbonded_f3t $c
 done
 # summary for bench.py (FETCH_SIZE and WRITE_SIZE are in KB; gfx950 tallies this kernel's 16- and 8-byte per-lane loads at half size)
+cd $R
 python3 - <<'PY'
 import csv, json, statistics, glob
 def med(c):

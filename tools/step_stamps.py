@@ -15,6 +15,8 @@ e = eng.Engine(s, rc=1.0, dt=0.002, nstlist=20, nstcalcenergy=10, tc_groups=tc, 
 for kv in filter(None, os.environ.get("MDX_DEBUG", "").split(",")):
     e.debug_set(int(kv.split("=")[0]), int(kv.split("=")[1], 0))
 e.step(2000); e.synchronize()
+for kv in filter(None, os.environ.get("MDX_DEBUG_LATE", "").split(",")):      # switches that break the physics: only for the stamped steps
+    e.debug_set(int(kv.split("=")[0]), int(kv.split("=")[1], 0))
 def stamped(nlead, nstamp, ntrail):
     """nlead steps, reset, nstamp stamped steps, ntrail more steps, all enqueued back to back"""
     e.synchronize()
@@ -34,4 +36,5 @@ for lead, label in ((3, "plain step (step %% 20 == 3)"), (10, "energy step (step
         print("%8.1f %8.1f  %6.1f  %s" % ((a - t0) / 100.0, (b - t0) / 100.0, (b - a) / 100.0, n))
 # average step period from stamps over 40 steps: prepare start of first vs last is not kept, so time it from the host
 import time
+if os.environ.get("MDX_DEBUG_LATE"): sys.exit(0)
 e.synchronize(); t0 = time.perf_counter(); e.step(2000); e.synchronize(); print("2000 steps: %.1f us/step" % ((time.perf_counter() - t0) / 2000 * 1e6))
