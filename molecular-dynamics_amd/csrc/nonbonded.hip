@@ -79,10 +79,11 @@ __device__ __forceinline__ float mdx_pmecorr(float w)
 // exp + erfc by the rational Ewald correction above.
 // ABL bits: 1, 2 remove arithmetic (timing experiments); 4 takes the Ewald correction g from the table `gtab` in LDS;
 // 8 (energy kernel) takes g and h = erf(z)/z from a float4 table.
+// 16: the LJ parameters of the i-atoms live in LDS (`ilj`, 64 float2 per wave) instead of 16 registers.
 // NI: i-clusters of the super-cluster held in registers at a time; NI = 4 walks the unit's entries twice (36 registers
 // fewer, j-atoms loaded and j-forces reduced twice), so that waves of other kernels fit beside the energy kernel.
 template <bool ENERGY, bool TIMED = false, int ABL = 0, int NI = 8>
-__device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nullptr)
+__device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nullptr, float2 *ilj = nullptr)
 {
     MDX_STAMP(A.dw, ENERGY ? 2 : 1);
     long long t_start = 0, w_start = 0; int n_units = 0, n_entries = 0;
@@ -149,7 +150,10 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
 #pragma unroll 1
         for (int half = 0; half < 8 / NI; half++) {
         const int c0 = half * NI;
-        float xi[NI], yi[NI], zi[NI], qi[NI], hsi[NI], sei[NI];
+        constexpr bool ILDS = (ABL & 16) != 0;
+        float xi[NI], yi[NI], zi[NI], qi[NI], hsi[ILDS ? 1 : NI], sei[ILDS ? 1 : NI];
+        float2 *myilj = ILDS ? ilj + (threadIdx.x >> 6) * 64 : nullptr;
+        if (ILDS) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // the previous pass has read its values
         float fix[NI], fiy[NI], fiz[NI];
 #pragma unroll
         for (int c = 0; c < NI; c++) {
@@ -158,9 +162,12 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
             const float2 l = A.lj_s[ia];
             xi[c] = p.x - S.x; yi[c] = p.y - S.y; zi[c] = p.z - S.z;
             qi[c] = p.w * MDX_ONE_4PI_EPS0;
-            hsi[c] = l.x; sei[c] = l.y;
+            if (ILDS) { if (tj == 0) myilj[c * 8 + ti] = l; } else { hsi[c] = l.x; sei[c] = l.y; }
             fix[c] = 0.0f; fiy[c] = 0.0f; fiz[c] = 0.0f;
         }
+        // (LDS operations of one wave execute in order; the fence only keeps the compiler from moving the reads of
+        // other lanes' values above the writes)
+        if (ILDS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         // Software pipeline over the entries: j-atoms and exclusion mask are requested one entry ahead
         int cj_n = __builtin_amdgcn_readlane(myent.cj, 0);
         float4 pj_n = A.xq_s[cj_n * 8 + tj];
@@ -212,8 +219,10 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                 const bool listed = GENERAL ? (((exh >> c) & 1u) != 0u) : true;   // false: excluded pair, Ewald correction only
                 const float rinv = __frsqrt_rn(r2);
                 const float rinv2 = rinv * rinv;
-                const float sg = hsi[c] + lj.x;
-                const float e4 = sei[c] * lj.y;
+                float hs_c, se_c;
+                if (ILDS) { const float2 li = myilj[c * 8 + ti]; hs_c = li.x; se_c = li.y; } else { hs_c = hsi[c]; se_c = sei[c]; }
+                const float sg = hs_c + lj.x;
+                const float e4 = se_c * lj.y;
                 const float s2 = sg * sg * rinv2;
                 const float s6 = s2 * s2 * s2;
                 const float t6 = e4 * s6;
@@ -373,6 +382,17 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __syncthreads();
     nb_body<false, false, 4>(A, (const float2 *)tab4);
 }
+// The same with the i-atoms' LJ parameters in LDS: 16 registers fewer, so that three such waves leave a SIMD room for
+// three waves of the co-running PME and bonded kernels instead of two.
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3tl(NbArgs A)
+{
+    __shared__ float4 tab4[MDX_GTAB_N / 2];
+    __shared__ float2 ilj[12 * 64];
+    const float4 *src = (const float4 *)A.gtab;
+    for (int k = threadIdx.x; k < MDX_GTAB_N / 2; k += 768) tab4[k] = src[k];
+    __syncthreads();
+    nb_body<false, false, 4 | 16>(A, (const float2 *)tab4, ilj);
+}
 // The same at 128 registers (a few spills): leaves half a SIMD's register file to co-running kernels.
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_f3t128(NbArgs A)
 {
@@ -395,10 +415,11 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_evt4(NbArgs A)
 {
     __shared__ float4 tab4[MDX_GTAB_N];
+    __shared__ float2 ilj[12 * 64];
     const float4 *src = (const float4 *)A.htab;
     for (int k = threadIdx.x; k < MDX_GTAB_N; k += 768) tab4[k] = src[k];
     __syncthreads();
-    nb_body<true, false, 8, 4>(A, (const float2 *)tab4);
+    nb_body<true, false, 8 | 16, 4>(A, (const float2 *)tab4, ilj);
 }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3_abl1(NbArgs A) { nb_body<false, false, 1>(A); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3_abl2(NbArgs A) { nb_body<false, false, 2>(A); }
@@ -449,7 +470,7 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
         else if (s->dbg & 0x100000) kern = k_nonbonded_f3_abl1;
         else if (s->dbg & 0x200000) kern = k_nonbonded_f3_abl2;
         else if ((s->dbg & 0x400000) || !s->gtab) kern = k_nonbonded_f3;
-        else { kern = (s->dbg & 0x800000) ? k_nonbonded_f3t128 : k_nonbonded_f3t; grid = dim3(256); block = dim3(768); }
+        else { kern = (s->dbg & 0x800000) ? k_nonbonded_f3t128 : ((s->dbg & 0x4000000) ? k_nonbonded_f3t : k_nonbonded_f3tl); grid = dim3(256); block = dim3(768); }
     }
     hipExtLaunchKernelGGL(kern, grid, block, 0, s->stream, ev_a, ev_b, 0, A);
     MDX_CHECK(s, hipGetLastError());
