@@ -287,6 +287,15 @@ def main():
                                    "sample": "%d leap-frog steps of the same %d-atom system with the float64 oracle "
                                              "(C cell-list nonbonded on %d OpenMP threads, numpy PME/bonded/SHAKE), %.1f s; "
                                              "own CPU restatement, not GROMACS" % (args.cpu_steps, s.natoms, threads, wall)}
+        # the same kernel launched back to back on the current pair list with nothing beside it (inside the step it shares
+        # the SIMDs with the PME and bonded kernels, which is what `achieved` above prices)
+        try:
+            alone_ms = e.debug_time_nonbonded(False, 30)
+            out["roofline"]["avg_launch_ms_alone"] = round(alone_ms, 5)
+            out["roofline"]["achieved_alone"] = round(flops / (alone_ms * 1e-3) / 1e12, 3)
+            out["roofline"]["frac_alone"] = round(flops / (alone_ms * 1e-3) / 1e12 / peak, 4)
+        except Exception as ex:
+            out["roofline"]["avg_launch_ms_alone"] = "failed: %s" % ex
         # HBM-side kernels, each timed alone on its stream with HIP events after the run (the state is scrap afterwards):
         # algorithmic bytes per launch / time against the 8 TB/s HBM peak
         try:

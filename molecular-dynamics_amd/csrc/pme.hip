@@ -642,7 +642,9 @@ int mdx_launch_pme_spread(mdx_system *s, hipStream_t st, bool signal)
         const int planes = K2 + 8;
         // slabs of planes so that a tile stays below ~48 KB and the launch has enough workgroups
         int nchunk = 1;
-        while ((size_t)((planes + nchunk - 1) / nchunk) * A.T0 * A.T1 * 4 > 48 * 1024 || (s->ncx * s->ncy * nchunk < 512 && nchunk < 8)) nchunk++;
+        static const size_t tile_kb = getenv("MDX_SPREAD_LDS_KB") ? (size_t)atoi(getenv("MDX_SPREAD_LDS_KB")) : 48;
+        static const int min_wg = getenv("MDX_SPREAD_MIN_WG") ? atoi(getenv("MDX_SPREAD_MIN_WG")) : 512;
+        while ((size_t)((planes + nchunk - 1) / nchunk) * A.T0 * A.T1 * 4 > tile_kb * 1024 || (s->ncx * s->ncy * nchunk < min_wg && nchunk < 16)) nchunk++;
         A.ppc = (planes + nchunk - 1) / nchunk;
         A.delta = (float)delta; A.grid = s->grid; A.v_home = s->dd_on ? s->v : nullptr;
         if (getenv("MDX_PME_NOTILE")) { A.T0 = 4; A.T1 = 4; }
