@@ -126,7 +126,8 @@ __global__ __launch_bounds__(1024) void k_sortcol(const int *__restrict__ col_co
                                                  float4 *__restrict__ xq_s, float2 *__restrict__ lj_s, int *__restrict__ perm,
                                                  int *__restrict__ perm_src, int *__restrict__ shift_s, int *__restrict__ molid_s,
                                                  int *__restrict__ sorted_of, float4 *__restrict__ bb_lo, float4 *__restrict__ bb_hi,
-                                                 float4 *__restrict__ sbb_lo, float4 *__restrict__ sbb_hi, int nsc_cap)
+                                                 float4 *__restrict__ sbb_lo, float4 *__restrict__ sbb_hi, int nsc_cap,
+                                                 const float4 *__restrict__ v_home)
 {
     __shared__ float kz[MDX_MAX_COL], ky[MDX_MAX_COL], kx[MDX_MAX_COL];
     __shared__ int id[MDX_MAX_COL];
@@ -186,7 +187,15 @@ __global__ __launch_bounds__(1024) void k_sortcol(const int *__restrict__ col_co
             lo[1] = fminf(lo[1], ky[t]); hi[1] = fmaxf(hi[1], ky[t]);
             lo[2] = fminf(lo[2], kz[t]); hi[2] = fmaxf(hi[2], kz[t]);
         }
-        bb_lo[sc0 * 8 + c] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+        // domain decomposition: w = 1 marks a cluster of halo atoms (inverse mass 0) and fillers only; pairs of two
+        // such clusters move no home atom and are left out of the list
+        float halo = v_home ? 1.0f : 0.0f;
+        if (v_home)
+            for (int k = 0; k < 8; k++) {
+                const int a = id[c * 8 + k];
+                if (a != 0x7fffffff && v_home[a].w != 0.0f) halo = 0.0f;
+            }
+        bb_lo[sc0 * 8 + c] = make_float4(lo[0], lo[1], lo[2], halo);
         bb_hi[sc0 * 8 + c] = make_float4(hi[0], hi[1], hi[2], 0.0f);
     }
     for (int sc = threadIdx.x; sc < nscol; sc += blockDim.x) {
@@ -198,7 +207,13 @@ __global__ __launch_bounds__(1024) void k_sortcol(const int *__restrict__ col_co
             lo[1] = fminf(lo[1], ky[t]); hi[1] = fmaxf(hi[1], ky[t]);
             lo[2] = fminf(lo[2], kz[t]); hi[2] = fmaxf(hi[2], kz[t]);
         }
-        sbb_lo[sc0 + sc] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+        float halo = v_home ? 1.0f : 0.0f;
+        if (v_home)
+            for (int k = 0; k < 64; k++) {
+                const int a = id[sc * 64 + k];
+                if (a != 0x7fffffff && v_home[a].w != 0.0f) halo = 0.0f;
+            }
+        sbb_lo[sc0 + sc] = make_float4(lo[0], lo[1], lo[2], halo);
         sbb_hi[sc0 + sc] = make_float4(hi[0], hi[1], hi[2], 0.0f);
     }
 }
@@ -344,7 +359,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
                     for (int step = 32; step; step >>= 1) if (row_first[wv][l + step] <= fl) l += step;
                     const int scj_l = row_scb[wv][l] + (fl - row_first[wv][l]);
                     if (central) ok = ok && (scj_l >= sci);
-                    if (ok) ok = bb_dist2(slo, shi, A.sbb_lo[scj_l], A.sbb_hi[scj_l]) < rl2;
+                    if (ok) { const float4 jl = A.sbb_lo[scj_l]; ok = bb_dist2(slo, shi, jl, A.sbb_hi[scj_l]) < rl2 && !(slo4.w != 0.0f && jl.w != 0.0f); }
                     unsigned long long m = __ballot(ok);
                     if (A.dbg & 4096) m = 0;
                     while (m) {
@@ -357,7 +372,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
                         const float4 xjv = A.xq_s[scj * 64 + lane];
                         const int ojv = A.perm[scj * 64 + lane];
                         const float bd2 = bb_dist2(ilo, ihi, jlo, jhi);
-                        bool okc = bd2 < rl2;
+                        bool okc = bd2 < rl2 && !(ilo4.w != 0.0f && jlo.w != 0.0f);
                         if (central && scj == sci) okc = okc && (tj >= ti);
                         const unsigned long long cm = __ballot(okc);
                         // boxes this close hold a pair within rlist almost surely: listed without the atom test
@@ -621,7 +636,8 @@ int mdx_search(mdx_system *s)
     hipLaunchKernelGGL(k_fill, dim3(nbk), dim3(256), 0, s->stream, s->n, s->atom_col, s->atom_slot, s->col_astart, s->col_atoms);
     hipLaunchKernelGGL(k_sortcol, dim3(ncol), dim3(1024), 0, s->stream, s->col_count, s->col_astart, s->col_scstart,
                        s->col_atoms, s->wrapped, s->x, s->lj, s->molid, s->xq_s, s->lj_s, s->perm, s->perm_src, s->shift_s,
-                       s->molid_s, s->sorted_of, s->bb_lo, s->bb_hi, s->sbb_lo, s->sbb_hi, s->npad / 64);
+                       s->molid_s, s->sorted_of, s->bb_lo, s->bb_hi, s->sbb_lo, s->sbb_hi, s->npad / 64,
+                       (const float4 *)(s->dd_on ? s->v : nullptr));
     hipLaunchKernelGGL(k_shiftvec, dim3(1), dim3(64), 0, s->stream, s->d, s->nshift, s->shift_ijk, s->shiftvec);
     ListArgs A;
     A.dro = s->d; A.d = s->d; A.ncx = ncx; A.ncy = ncy; A.col_scstart = s->col_scstart; A.xq_s = s->xq_s; A.perm = s->perm;

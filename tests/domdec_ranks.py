@@ -27,6 +27,7 @@ def decomposed(world, nst, rest, d):
             dd = domdec.DecomposedWater(s, device=0, rc=1.0, dt=0.002, nstlist=10, ref_t=None, rlist=1.1, transport=hub.port(rank))
             info = dict(dims=dd.dims, home=dd.n_home, halo=dd.n_halo, cap=dd.cap)
             dd.step(nst); dd.synchronize()
+            info["list_tiles"] = dd.engine.list_stats()["cluster_pairs"]
             x, v = dd.gather_state()
             if rank == 0:
                 out.update(x=x, v=v, info=info)
