@@ -222,8 +222,9 @@ int mdx_get_kernel_timing(mdx_system *sys, double *nb_ms_total, long long *nb_la
  * nonbonded kernel on the current pair list; select a kernel variant (key 1: 1 or 2). */
 int mdx_debug_time_nonbonded(mdx_system *sys, int energy, int iters, double *avg_ms);
 int mdx_debug_set(mdx_system *sys, int key, int value);
-/* One launch of the force-only nonbonded kernel with per-wave clocks: 8 values per wave (shader clock
- * at start and end, 100 MHz wall clock at start and end, work units, list entries, HW_ID, XCC_ID). */
+/* One launch of the force-only nonbonded kernel with per-wave clocks: 10 values per wave (shader clock
+ * at start and end, 100 MHz wall clock at start and end, work units, list entries, HW_ID, XCC_ID,
+ * 8x8 tiles tested, tiles evaluated). */
 /* Diagnostic build (-DMDX_STAMPS) only: reset, or read, the per-kernel first-start / last-end time stamps. */
 int mdx_debug_stamps(mdx_system *sys, int reset, long long *out48);
 int mdx_debug_wave_times(mdx_system *sys, long long *out, int max_waves, int *nwaves);

@@ -86,7 +86,7 @@ template <bool ENERGY, bool TIMED = false, int ABL = 0, int NI = 8>
 __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nullptr, float2 *ilj = nullptr)
 {
     MDX_STAMP(A.dw, ENERGY ? 2 : 1);
-    long long t_start = 0, w_start = 0; int n_units = 0, n_entries = 0;
+    long long t_start = 0, w_start = 0; int n_units = 0, n_entries = 0, n_tested = 0, n_eval = 0;
     if (TIMED) { t_start = clock64(); w_start = wall_clock64(); }
     const int lane = threadIdx.x & 63;
     const int ti = lane & 7, tj = lane >> 3;
@@ -214,7 +214,9 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                 if (GENERAL) within = within && ((live >> c) & 1u);
                 // the list is built with a buffer: an 8x8 tile none of whose pairs is inside the
                 // cutoff right now costs only the distance test (wave-uniform skip)
+                if (TIMED) n_tested++;
                 if (__builtin_amdgcn_ballot_w64(within) == 0ull) return;
+                if (TIMED) n_eval++;
                 did = true;
                 const bool listed = GENERAL ? (((exh >> c) & 1u) != 0u) : true;   // false: excluded pair, Ewald correction only
                 const float rinv = __frsqrt_rn(r2);
@@ -338,7 +340,8 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
         } else unit_n = nwork;
     }
     if (TIMED && (threadIdx.x & 63) == 0) {
-        long long *o = A.wave_t + 8 * (size_t)wave_id;
+        long long *o = A.wave_t + 10 * (size_t)wave_id;
+        o[8] = n_tested; o[9] = n_eval;
         o[0] = t_start; o[1] = clock64(); o[2] = w_start; o[3] = wall_clock64(); o[4] = n_units; o[5] = n_entries;
         o[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4); o[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_ID, XCC_ID
     }
@@ -502,22 +505,22 @@ extern "C" int mdx_debug_time_nonbonded(mdx_system *s, int energy, int iters, do
     return rc;
 }
 
-// Diagnostic: one launch of the force-only kernel (3 waves/SIMD shape) with per-wave clocks; out holds 8 values per wave
-// (shader clock at start and end, 100 MHz wall clock at start and end, work units, list entries, HW_ID, XCC_ID).
+// Diagnostic: one launch of the force-only kernel (3 waves/SIMD shape) with per-wave clocks; out holds 10 values per wave
+// (shader clock at start and end, 100 MHz wall clock at start and end, work units, list entries, HW_ID, XCC_ID, 8x8 tiles tested, tiles evaluated).
 extern "C" int mdx_debug_wave_times(mdx_system *s, long long *out, int max_waves, int *nwaves)
 {
     (void)hipSetDevice(s->device);
     const int nw = 256 * 3 * 4;
     if (!out || max_waves < nw) { s->err = "mdx_debug_wave_times: buffer too small"; return MDX_ERR_ARG; }
     long long *d = nullptr;
-    MDX_CHECK(s, hipMalloc((void **)&d, sizeof(long long) * 8 * nw));
-    MDX_CHECK(s, hipMemsetAsync(d, 0, sizeof(long long) * 8 * nw, s->stream));
+    MDX_CHECK(s, hipMalloc((void **)&d, sizeof(long long) * 10 * nw));
+    MDX_CHECK(s, hipMemsetAsync(d, 0, sizeof(long long) * 10 * nw, s->stream));
     const int keep_var = s->nb_variant; const bool keep = s->time_nb;
     s->nb_variant = 33; s->time_nb = false; s->nb_wave_t = d;
     (void)hipMemsetAsync((char *)s->d + offsetof(DevState, nb_head), 0, sizeof(int) * 8 * 32, s->stream);
     int rc = mdx_launch_nonbonded(s, false, MDX_F_NONBONDED | MDX_F_EXCL);
     s->nb_wave_t = nullptr; s->nb_variant = keep_var; s->time_nb = keep;
-    if (rc == MDX_OK && hipMemcpyAsync(out, d, sizeof(long long) * 8 * nw, hipMemcpyDeviceToHost, s->stream) != hipSuccess) rc = MDX_ERR_HIP;
+    if (rc == MDX_OK && hipMemcpyAsync(out, d, sizeof(long long) * 10 * nw, hipMemcpyDeviceToHost, s->stream) != hipSuccess) rc = MDX_ERR_HIP;
     if (hipStreamSynchronize(s->stream) != hipSuccess) rc = MDX_ERR_HIP;
     (void)hipFree(d);
     if (nwaves) *nwaves = nw;

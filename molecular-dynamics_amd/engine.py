@@ -484,7 +484,7 @@ class Engine:
         return ms.value
 
     def debug_wave_times(self):
-        buf = np.zeros((4096, 8), dtype=np.int64); nw = ctypes.c_int(0)
+        buf = np.zeros((4096, 10), dtype=np.int64); nw = ctypes.c_int(0)
         self._call("mdx_debug_wave_times", buf.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), 4096, ctypes.byref(nw))
         return buf[:nw.value]
 

@@ -18,7 +18,8 @@ for dyn, sp in ((0, 0), (1, 0), (1, 1), (1, 2), (1, 3), (2, 1), (2, 2), (2, 3), 
 for rep, (dyn, sp) in enumerate(((1, 2), (2, 2))):
     e.debug_set(3, dyn); e.debug_set(4, sp)
     t = e.debug_wave_times()
-    c0, c1, w0, w1, nu, ne, hw, xcc = t.T
+    c0, c1, w0, w1, nu, ne, hw, xcc, ntest, nev = t.T
+    print("tiles tested %d, evaluated %d (%.1f %%), entries %d" % (ntest.sum(), nev.sum(), 100.0 * nev.sum() / max(ntest.sum(), 1), ne.sum()))
     span_c = 1; span_w = (w1.max() - w0[w0 > 0].min()) / 100.0
     dur = (c1 - c0)
     print("launch span %.1f us (wall clock), %d shader cycles -> %.2f GHz" % (span_w, span_c, span_c / span_w / 1e3))
