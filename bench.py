@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prep-steps", type=int, default=2000)
     ap.add_argument("--no-output", action="store_true", help="diagnostic: skip the trajectory output the .mdp asks for")
+    ap.add_argument("--ring", type=int, default=8, help="pinned trajectory-frame slots between the GPU and the encoder threads")
     ap.add_argument("--encoders", type=int, default=3, help="host threads compressing trajectory frames")
     args = ap.parse_args()
 
@@ -181,8 +182,8 @@ def main():
         from mdx.output import FramePipeline
         xtc_path = os.path.join(tempfile.gettempdir(), "mdx_bench_rank%d_%d.xtc" % (rank, os.getpid()))
         xtc = traj.XtcWriter(xtc_path, s.natoms, precision=1000.0)
-        e.frame_ring(8)
-        pipe = FramePipeline(e, 8, xtc, None, None, dt, 0.0, nthreads=args.encoders)
+        e.frame_ring(args.ring)
+        pipe = FramePipeline(e, args.ring, xtc, None, None, dt, 0.0, nthreads=args.encoders)
     e.enable_kernel_timing(True)
     torch.cuda.synchronize()
     if use_dist:

@@ -584,7 +584,7 @@ int mdx_join(mdx_system *s)
     MDX_CHECK(s, hipEventRecord(s->ev_bond, s->st_bond));
     MDX_CHECK(s, hipStreamWaitEvent(s->stream, s->ev_bond, 0));
     MDX_CHECK(s, hipStreamWaitEvent(s->stream, s->ev_pme, 0));
-    return MDX_OK;
+    return mdx_launch_pme_gather_pending(s);
 }
 
 extern "C" int mdx_compute_forces(mdx_system *s, unsigned terms)
@@ -845,7 +845,8 @@ extern "C" int mdx_debug_time_stage(mdx_system *s, int stage, int iters, double 
     if (stage == 3) st = s->st_bond;
     hipEvent_t a, b;
     MDX_CHECK(s, hipEventCreate(&a)); MDX_CHECK(s, hipEventCreate(&b));
-    const int saved = s->dbg;
+    const int saved = s->dbg, saved_gather = s->gather_on_main;
+    s->gather_on_main = 0;          // the whole chain on its own stream while it is timed
     if (stage == 6) s->dbg |= 256;
     if (stage == 7) s->dbg |= 2048;
     auto run = [&]() -> int {
@@ -866,7 +867,7 @@ extern "C" int mdx_debug_time_stage(mdx_system *s, int stage, int iters, double 
     float ms = 0.0f;
     MDX_CHECK(s, hipEventElapsedTime(&ms, a, b));
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-    s->dbg = saved;
+    s->dbg = saved; s->gather_on_main = saved_gather;
     s->f_dirty = true;
     MDX_CHECK(s, hipDeviceSynchronize());
     if (avg_ms) *avg_ms = ms / (iters > 0 ? iters : 1);

@@ -108,6 +108,8 @@ struct mdx_system {
     int dbg = 0;                       // diagnostic ablation bits (mdx_debug_set key 2)
     int nb_dyn = 1;                    // nonbonded kernel: rounds' worth of cheap units scheduled dynamically (mdx_debug_set key 3)
     int nb_dyn_split = 0;              // ... in 2^nb_dyn_split parts per unit (mdx_debug_set key 4)
+    int gather_on_main = 0;            // PME gather behind the nonbonded kernel on the main stream: measured slower, the nonbonded kernel ends last (mdx_debug_set key 8)
+    const float *gather_pending = nullptr;
     int spread_on_main = 0;            // charge spreading on the main stream ahead of the nonbonded kernel: measured slower (mdx_debug_set key 7)
     int bond_on_main = 0;              // bonded and pull kernels behind the nonbonded kernel on the main stream (mdx_debug_set key 6)
     int early_fork = 1;                // release the side streams of a plain step right after the previous update (mdx_debug_set key 5)
@@ -248,6 +250,7 @@ int mdx_launch_prepare(mdx_system *s, bool fork = false);
 int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms);
 int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done = false);
 int mdx_launch_pme_spread(mdx_system *s, hipStream_t st, bool signal);
+int mdx_launch_pme_gather_pending(mdx_system *s);
 int mdx_launch_bonded(mdx_system *s, bool energy, unsigned flags);
 int mdx_launch_pull(mdx_system *s, bool log_now, bool energy);
 int mdx_launch_update(mdx_system *s, bool do_tc, bool do_pr, bool virial);

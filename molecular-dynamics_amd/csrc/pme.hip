@@ -660,6 +660,18 @@ int mdx_launch_pme_spread(mdx_system *s, hipStream_t st, bool signal)
     return MDX_OK;
 }
 
+// The gather deferred to the main stream (see gather_on_main): called by the join once that stream waits for the transforms.
+int mdx_launch_pme_gather_pending(mdx_system *s)
+{
+    if (!s->gather_pending) return MDX_OK;
+    const int nb = (int)(((size_t)s->n * 16 + 255) / 256);
+    hipLaunchKernelGGL(k_pme_gather, dim3(nb), dim3(256), 0, s->stream, s->n, (const float4 *)s->x, (const DevState *)s->d,
+                       s->K[0], s->K[1], s->K[2], s->gather_pending, s->f_pme);
+    s->gather_pending = nullptr;
+    MDX_CHECK(s, hipGetLastError());
+    return MDX_OK;
+}
+
 int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done)
 {
     if (!s->have_pme) return MDX_OK;
@@ -723,6 +735,14 @@ int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done)
     else
         hipLaunchKernelGGL(k_pme_solve<false>, dim3(nbs), dim3(256), 0, s->st_pme, s->cgrid, s->d, s->d, K0, K1, K2, s->bmod[0], s->bmod[1], s->bmod[2], s->beta);
     if (hipfftExecC2R(s->plan_c2r, (hipfftComplex *)s->cgrid, s->grid) != HIPFFT_SUCCESS) { s->err = "hipfftExecC2R failed"; return MDX_ERR_HIP; }
+    }
+    if (s->gather_on_main) {
+        // the gather follows the nonbonded kernel in the main queue (released by the end of the transforms): the update
+        // then starts one in-queue gap after it instead of one cross-queue wake-up after the PME stream
+        MDX_CHECK(s, hipEventRecord(s->ev_pme, s->st_pme));
+        s->pme_signalled = true;
+        s->gather_pending = potential;
+        return MDX_OK;
     }
     // the completion signal of the last kernel of the chain is the event the main stream waits for
     hipExtLaunchKernelGGL(k_pme_gather, dim3(nb), dim3(256), 0, s->st_pme, nullptr, s->ev_pme, 0, s->n, (const float4 *)s->x,
