@@ -1,5 +1,6 @@
 // C ABI of libmdx.so (declared in include/mdx.h) and the per-step launch sequence.
 #include "mdx_internal.h"
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -70,6 +71,8 @@ extern "C" mdx_system *mdx_create(int device, int natoms)
               hipEventCreateWithFlags(&s->ev_bond, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_spread, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
     const int n = natoms;
+    // MDX_NB_DYN=0 in the environment selects the static deal of the nonbonded kernel (processes sharing one GPU)
+    if (const char *e = getenv("MDX_NB_DYN")) s->nb_dyn = atoi(e);
     s->ncol_cap = n / 128 + 256;
     s->npad = ((n + 63) / 64 + s->ncol_cap) * 64;
     s->cj_cap = (s->npad / 64) * MDX_CJ_PER_SC;
