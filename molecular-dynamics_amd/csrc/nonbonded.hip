@@ -195,11 +195,15 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
             // `live` bit c: this lane's pair with i-cluster c is evaluated at all. In the tile of a
             // cluster with itself only tj > ti is (each pair once, no self pair); listed pairs need
             // do_pairs, excluded pairs need do_excl.
-            unsigned live = do_pairs ? ex : 0u;
-            if (do_excl) live |= ~ex & 0xFFu;
-            if (is_central && (cj >> 3) == sci && tj <= ti) live &= ~(1u << (cj & 7));
-            live >>= c0;
-            const unsigned exh = ex >> c0;
+            const bool general = slot != 0u || !do_pairs || (is_central && (cj >> 3) == sci);    // wave-uniform
+            unsigned live = 0xFFu, exh = 0xFFu;
+            if (general) {          // plain entries never look at these
+                live = do_pairs ? ex : 0u;
+                if (do_excl) live |= ~ex & 0xFFu;
+                if (is_central && (cj >> 3) == sci && tj <= ti) live &= ~(1u << (cj & 7));
+                live >>= c0;
+                exh = ex >> c0;
+            }
             float fjx = 0.0f, fjy = 0.0f, fjz = 0.0f;
             bool did = false;           // wave-uniform: some tile of this entry had a pair inside the cutoff
             // One 8x8 tile: i-cluster c against the j-cluster. GENERAL tiles look at the exclusion and
@@ -289,7 +293,6 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                     vyy = fmaf(dy, fy, vyy); vyz = fmaf(dy, fz, vyz); vzz = fmaf(dz, fz, vzz);
                 }
             };
-            const bool general = slot != 0u || !do_pairs || (is_central && (cj >> 3) == sci);    // wave-uniform
             if (!general) {
 #pragma unroll
                 for (int c = 0; c < NI; c++)
