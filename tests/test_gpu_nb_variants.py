@@ -1,0 +1,38 @@
+"""The selectable variants of the nonbonded kernel agree with the default: tabulated against analytic Ewald correction,
+ticket queues against the static deal of the work units, and the energy kernel holding four i-clusters against eight.
+(The default itself is checked against the oracle in test_gpu_parity.py.)"""
+import numpy as np
+import pytest
+
+import mdx  # noqa: F401
+from mdx import engine as eng
+
+pytestmark = pytest.mark.gpu
+
+
+def relrms(a, b):
+    return float(np.sqrt(((a - b) ** 2).sum() / (b ** 2).sum()))
+
+
+def test_variants_agree(small_complex):
+    s = small_complex
+    e = eng.Engine(s, rc=1.0, nstcalcenergy=1)
+    try:
+        f0, en0 = e.compute(eng.F_NONBONDED | eng.F_EXCL)
+        for key, val, label in ((2, 0x400000, "analytic"), (2, 0x1000000, "eight i-clusters"), (3, 0, "static deal"), (3, 3, "three dynamic rounds")):
+            e.debug_set(key, val)
+            f, en = e.compute(eng.F_NONBONDED | eng.F_EXCL)
+            e.debug_set(key, 0 if key == 2 else 1)
+            assert relrms(f, f0) < 3e-6, label
+            # (the short-range Coulomb sum nearly cancels in a neutral system: the scale is the largest of the terms)
+            scale = max(abs(en0[t]) for t in ("LJ", "COUL_SR", "COUL_EXCL"))
+            for term in ("LJ", "COUL_SR", "COUL_EXCL"):
+                assert abs(en[term] - en0[term]) < 1e-5 * scale, (label, term, en[term], en0[term])
+        # force-only launches (the step loop) against the energy launch: 40 steps from identical states
+        x0, v0, box = e.get_state()
+        e.step(40); xa, _, _ = e.get_state()
+        e.set_state(x0, v0, box); e.set_step(0); e.debug_set(2, 0x400000)
+        e.step(40); xb, _, _ = e.get_state()
+        assert np.abs(xa - xb).max() < 5e-4
+    finally:
+        e.close()
