@@ -412,10 +412,11 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_evt(NbArgs A)
 {
     __shared__ float4 tab4[MDX_GTAB_N];
+    __shared__ float2 ilj[12 * 64];
     const float4 *src = (const float4 *)A.htab;
     for (int k = threadIdx.x; k < MDX_GTAB_N; k += 768) tab4[k] = src[k];
     __syncthreads();
-    nb_body<true, false, 8>(A, (const float2 *)tab4);
+    nb_body<true, false, 8 | 16>(A, (const float2 *)tab4, ilj);
 }
 // The same holding four i-clusters at a time: fits beside the kernels of the PME and bonded streams.
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_evt4(NbArgs A)
