@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prep-steps", type=int, default=2000)
     ap.add_argument("--no-output", action="store_true", help="diagnostic: skip the trajectory output the .mdp asks for")
+    ap.add_argument("--chunk", type=int, default=0, help="diagnostic with --no-output: steps per mdx_step call")
     ap.add_argument("--ring", type=int, default=8, help="pinned trajectory-frame slots between the GPU and the encoder threads")
     ap.add_argument("--encoders", type=int, default=3, help="host threads compressing trajectory frames")
     args = ap.parse_args()
@@ -199,6 +200,9 @@ def main():
             n = min(args.steps - done, nst_xtc - e.get_step() % nst_xtc)
             e.step(n)
             done += n
+    elif args.chunk > 0:      # diagnostic: the call pattern of the output loop without the output
+        for _ in range(args.steps // args.chunk):
+            e.step(args.chunk)
     else:
         e.step(args.steps)
     e.synchronize(); torch.cuda.synchronize()
