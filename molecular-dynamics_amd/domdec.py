@@ -170,51 +170,79 @@ class Transport:
 class ThreadTransport:
     """The same collectives between `world` domains that live in one process, one thread each (rehearsal and tests
     on a single GPU: processes that share a GPU are time-sliced far more coarsely than a step lasts, threads of one
-    process are not). Create one `ThreadTransport.Hub(world)` and hand `hub.port(rank)` to each thread's domain."""
+    process are not). Only one of the threads runs at any time: each holds the hub's lock while it computes and hands
+    it over while it waits for the others at a collective, so the handles never talk to the GPU runtime concurrently
+    (streams of several handles share a few hardware queues, and concurrent host threads inside the runtime were seen
+    to block each other for good). `Hub.run(fn)` starts `fn(rank, transport)` on `world` threads under that rule."""
 
     class Hub:
         def __init__(self, world: int):
             import threading
             self.world = world
             self.barrier = threading.Barrier(world)
+            self.lock = threading.Lock()
             self.slots = [None] * world
 
         def port(self, rank: int):
             return ThreadTransport(self, rank)
 
+        def run(self, fn):
+            """fn(rank, transport) on one thread per domain; returns the list of results, re-raises the first error."""
+            import threading
+            res, err = [None] * self.world, []
+
+            def body(rank):
+                with self.lock:
+                    try:
+                        res[rank] = fn(rank, self.port(rank))
+                    except BaseException as e:          # a failing domain must not leave the others at a barrier
+                        err.append(e)
+                        self.barrier.abort()
+            th = [threading.Thread(target=body, args=(r,)) for r in range(self.world)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            if err:
+                raise err[0]
+            return res
+
     def __init__(self, hub, rank: int):
         self.hub, self.rank, self.world, self.staged, self.group = hub, rank, hub.world, False, None
+        self.serial = True          # DecomposedWater drains its handle before it hands the GPU over
 
-    def _publish(self, obj):
+    def _meet(self):
+        """All work of this thread complete, then wait for the others with the lock handed over."""
         if torch.cuda.is_available():
             torch.cuda.synchronize()
-        self.hub.slots[self.rank] = obj
-        self.hub.barrier.wait()
-
-    def _done(self):
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
-        self.hub.barrier.wait()
+        self.hub.lock.release()
+        try:
+            self.hub.barrier.wait()
+        finally:
+            self.hub.lock.acquire()
 
     def all_gather(self, t):
-        self._publish(t)
+        self.hub.slots[self.rank] = t
+        self._meet()
         out = [s.clone() for s in self.hub.slots]
-        self._done()
+        self._meet()
         return out
 
     def all_reduce_sum_(self, t):
-        self._publish(t.clone())
+        self.hub.slots[self.rank] = t.clone()
+        self._meet()
         total = torch.stack(list(self.hub.slots)).sum(0)
-        self._done()
+        self._meet()
         t.copy_(total)
         return t
 
     def exchange(self, send, recv):
-        self._publish(send)
+        self.hub.slots[self.rank] = send
+        self._meet()
         for r in range(self.world):
             if r != self.rank and recv[r].numel():
                 recv[r].copy_(self.hub.slots[r][self.rank])
-        self._done()
+        self._meet()
 
 
 class _DevArray:
@@ -373,6 +401,22 @@ class DecomposedWater:
             self.engine.dd_unpack(MOL_ATOMS * self.n_home, MOL_ATOMS * self.n_halo, self.recv_buf.data_ptr())
 
     # ------------------------------------------------------------------ stepping
+    def _exclusive(self):
+        """With the in-process transport the handle is drained (all its streams idle) when the block ends, before the
+        GPU is handed to another domain's thread; otherwise a no-op."""
+        import contextlib
+        if not getattr(self.tr, "serial", False):
+            return contextlib.nullcontext()
+        dd = self
+
+        @contextlib.contextmanager
+        def drained():
+            try:
+                yield
+            finally:
+                dd.engine.synchronize()
+        return drained()
+
     def step(self, nsteps: int):
         import os
         dbg = bool(os.environ.get("MDX_DD_DEBUG"))
@@ -384,12 +428,15 @@ class DecomposedWater:
                 say("repartition"); self.repartition()
             elif self.steps_since_partition > 0:
                 say("halo refresh"); self._refresh_halo()
-            say("begin"); self.engine.dd_step_begin()
+            with self._exclusive():
+                say("begin"); self.engine.dd_step_begin()
+                if self.world > 1:
+                    say("wait spread"); self.engine.dd_wait_spread()
             if self.world > 1:
-                say("wait spread"); self.engine.dd_wait_spread()
                 say("grid sum"); self.tr.all_reduce_sum_(self.grid_t)
                 torch.cuda.synchronize(self.dev)
-            say("end"); self.engine.dd_step_end()
+            with self._exclusive():
+                say("end"); self.engine.dd_step_end()
             self.steps_since_partition += 1
             self.nsteps_done += 1
 

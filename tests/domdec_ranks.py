@@ -7,7 +7,7 @@ JSON line with
    relative RMS difference of the velocities between the two runs;
  - trajectory agreement after `steps` steps (pair-list lifetime 10: the partition is renewed on the way).
 python tests/domdec_ranks.py [world] [steps] [box d]"""
-import json, os, sys, threading
+import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
@@ -17,29 +17,19 @@ def decomposed(world, nst, rest, d):
     import mdx
     from mdx import synth, domdec
     hub = domdec.ThreadTransport.Hub(world)
-    out, err = {}, []
 
-    def rank_main(rank):
-        try:
-            s = synth.water_box(d=d)
-            if rest:
-                s.v = np.zeros_like(s.v)
-            dd = domdec.DecomposedWater(s, device=0, rc=1.0, dt=0.002, nstlist=10, ref_t=None, rlist=1.1, transport=hub.port(rank))
-            info = dict(dims=dd.dims, home=dd.n_home, halo=dd.n_halo, cap=dd.cap)
-            dd.step(nst); dd.synchronize()
-            info["list_tiles"] = dd.engine.list_stats()["cluster_pairs"]
-            x, v = dd.gather_state()
-            if rank == 0:
-                out.update(x=x, v=v, info=info)
-            dd.close()
-        except BaseException as e:      # a failing rank must not leave the others waiting at a barrier
-            err.append(e); hub.barrier.abort()
-    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
-    for t in th: t.start()
-    for t in th: t.join()
-    if err:
-        raise err[0]
-    return out
+    def rank_main(rank, transport):
+        s = synth.water_box(d=d)
+        if rest:
+            s.v = np.zeros_like(s.v)
+        dd = domdec.DecomposedWater(s, device=0, rc=1.0, dt=0.002, nstlist=10, ref_t=None, rlist=1.1, transport=transport)
+        info = dict(dims=dd.dims, home=dd.n_home, halo=dd.n_halo, cap=dd.cap)
+        dd.step(nst); dd.synchronize()
+        info["list_tiles"] = dd.engine.list_stats()["cluster_pairs"]
+        x, v = dd.gather_state()
+        dd.close()
+        return dict(x=x, v=v, info=info)
+    return hub.run(rank_main)[0]
 
 
 def main(world=2, steps=12, d=7.0):
