@@ -96,10 +96,16 @@ int mdx_set_dihedrals(mdx_system *sys, int n, const int *idx, const float *phi0_
 int mdx_set_pairs14(mdx_system *sys, int n, const int *idx, const float *c6, const float *c12,
                     const float *qq);
 /* `[ position_restraints ]` under `define = -DPOSRES` (/root/reference/mdp/nvt_complex.mdp:2);
- * ref = the `grompp -r` coordinates; refcoord_scaling 0 no / 1 all / 2 com
- * (/root/reference/mdp/npt_complex.mdp:72). */
+ * ref = the `grompp -r` coordinates; refcoord_scaling 0 no / 1 all (/root/reference/mdp/npt_complex.mdp:72:
+ * every reference position scales with the box) / 2 com (/root/reference/mdp/npt.mdp:40: the references move
+ * rigidly with the scaled plain average of their positions). The mode also sets the arm of the restraint
+ * virial: displacement only (all), plus the reference relative to that average (com), plus the whole
+ * reference (no). */
 int mdx_set_posres(mdx_system *sys, int n, const int *idx, const float *ref_xyz, const float *k_xyz,
                    int refcoord_scaling);
+/* Current restraint reference positions (n x 3, in the order given to mdx_set_posres), as pressure coupling
+ * has moved them; what a checkpoint has to carry for `refcoord_scaling` (same keys as above). */
+int mdx_get_posres_ref(mdx_system *sys, float *ref_xyz);
 /* `[ settles ]` (tip3p.itp): triples (O,H,H). */
 int mdx_set_settles(mdx_system *sys, int n, const int *idx, float d_oh, float d_hh);
 /* `constraints = h-bonds`, `constraint_algorithm = lincs`, `lincs_order`, `lincs_iter`

@@ -134,7 +134,7 @@ __device__ __forceinline__ void d_pairs14(int t, int n, const int2 *__restrict__
 template <bool ENERGY>
 __device__ __forceinline__ void d_posres(int t, int n, const int *__restrict__ idx, const float4 *__restrict__ ref,
                                                 const float4 *__restrict__ kk, const float4 *__restrict__ x,
-                                                float *__restrict__ f, DevState *dw)
+                                                float *__restrict__ f, DevState *dw, int refcoord_scaling)
 {
     double e = 0.0; float v9[9] = { 0 };
     if (t < n) {
@@ -144,7 +144,16 @@ __device__ __forceinline__ void d_posres(int t, int n, const int *__restrict__ i
         d = mdx_min_image(dw->box, d);
         const float3 fi = make_float3(-k.x * d.x, -k.y * d.y, -k.z * d.z);
         add_force(f, a, fi);
-        if (ENERGY) { e = 0.5 * (k.x * d.x * d.x + k.y * d.y * d.y + k.z * d.z * d.z); outer_acc(v9, d, fi); }
+        if (ENERGY) {
+            e = 0.5 * (k.x * d.x * d.x + k.y * d.y * d.y + k.z * d.z * d.z);
+            // The virial arm is the displacement plus the part of the reference that does not scale with the box:
+            // nothing (`all`), the reference relative to the restraint centre (`com`), the whole reference (`no`).
+            float3 arm = d;
+            if (refcoord_scaling == 0) arm = d + xyz(r);
+            else if (refcoord_scaling == 2)
+                arm = d + xyz(r) - make_float3((float)dw->posres_com[0], (float)dw->posres_com[1], (float)dw->posres_com[2]);
+            outer_acc(v9, arm, fi);
+        }
     }
     if (ENERGY) accum_ev(e, v9, dw, MDX_E_POSRES);
 }
@@ -159,7 +168,7 @@ struct BondedArgs {
     int nangles; const int4 *angle_ijk; const float2 *angle_p;
     int ndih; const int4 *dih_ijkl; const float4 *dih_p;
     int npairs; const int2 *pair_ij; const float4 *pair_p;
-    int nposres; const int *posres_idx; const float4 *posres_ref; const float4 *posres_k;
+    int nposres; const int *posres_idx; const float4 *posres_ref; const float4 *posres_k; int refcoord_scaling;
     const float4 *x; float *f; DevState *dw;
 };
 
@@ -172,7 +181,7 @@ __global__ __launch_bounds__(256) void k_bonded(BondedArgs A)
     else if (b < A.nb[2]) d_angles<ENERGY>((b - A.nb[1]) * 256 + threadIdx.x, A.nangles, A.angle_ijk, A.angle_p, A.x, A.f, A.dw);
     else if (b < A.nb[3]) d_dihedrals<ENERGY>((b - A.nb[2]) * 256 + threadIdx.x, A.ndih, A.dih_ijkl, A.dih_p, A.x, A.f, A.dw);
     else if (b < A.nb[4]) d_pairs14<ENERGY>((b - A.nb[3]) * 256 + threadIdx.x, A.npairs, A.pair_ij, A.pair_p, A.x, A.f, A.dw);
-    else d_posres<ENERGY>((b - A.nb[4]) * 256 + threadIdx.x, A.nposres, A.posres_idx, A.posres_ref, A.posres_k, A.x, A.f, A.dw);
+    else d_posres<ENERGY>((b - A.nb[4]) * 256 + threadIdx.x, A.nposres, A.posres_idx, A.posres_ref, A.posres_k, A.x, A.f, A.dw, A.refcoord_scaling);
 }
 
 int mdx_launch_bonded(mdx_system *s, bool energy, unsigned flags)
@@ -184,6 +193,7 @@ int mdx_launch_bonded(mdx_system *s, bool energy, unsigned flags)
     A.ndih = bo ? s->ndih : 0; A.dih_ijkl = s->dih_ijkl; A.dih_p = s->dih_p;
     A.npairs = bo ? s->npairs : 0; A.pair_ij = s->pair_ij; A.pair_p = s->pair_p;
     A.nposres = pr ? s->nposres : 0; A.posres_idx = s->posres_idx; A.posres_ref = s->posres_ref; A.posres_k = s->posres_k;
+    A.refcoord_scaling = s->refcoord_scaling;
     A.x = s->x; A.f = s->f; A.dw = s->d;
     const int cnt[5] = { A.nbonds, A.nangles, A.ndih, A.npairs, A.nposres };
     int acc = 0;

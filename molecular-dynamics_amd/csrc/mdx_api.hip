@@ -262,9 +262,25 @@ extern "C" int mdx_set_posres(mdx_system *s, int n, const int *idx, const float 
         kk[a] = make_float4(k[3 * a], k[3 * a + 1], k[3 * a + 2], 0.0f);
     }
     s->nposres = n; s->refcoord_scaling = refcoord_scaling;
+    double com[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int a = 0; a < n; a++) for (int c = 0; c < 3; c++) com[c] += ref[3 * a + c];
+    for (int c = 0; c < 3; c++) com[c] = com[3 + c] = n ? com[c] / n : 0.0;
+    MDX_CHECK(s, hipMemcpy((char *)s->d + offsetof(DevState, posres_com), com, sizeof(com), hipMemcpyHostToDevice));
     rc = dev_upload(s, &s->posres_idx, id); if (rc) return rc;
     rc = dev_upload(s, &s->posres_ref, r); if (rc) return rc;
     return dev_upload(s, &s->posres_k, kk);
+}
+
+extern "C" int mdx_get_posres_ref(mdx_system *s, float *ref_xyz)
+{
+    (void)hipSetDevice(s->device);
+    ARG_CHECK(s, s->nposres == 0 || ref_xyz, "mdx_get_posres_ref: null output");
+    if (s->nposres == 0) return MDX_OK;
+    std::vector<float4> r(s->nposres);
+    MDX_CHECK(s, hipStreamSynchronize(s->stream));
+    MDX_CHECK(s, hipMemcpy(r.data(), s->posres_ref, sizeof(float4) * s->nposres, hipMemcpyDeviceToHost));
+    for (int a = 0; a < s->nposres; a++) { ref_xyz[3 * a] = r[a].x; ref_xyz[3 * a + 1] = r[a].y; ref_xyz[3 * a + 2] = r[a].z; }
+    return MDX_OK;
 }
 
 extern "C" int mdx_set_settles(mdx_system *s, int n, const int *idx, float doh, float dhh)

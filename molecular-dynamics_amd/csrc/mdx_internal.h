@@ -60,6 +60,9 @@ struct DevState {
     double vir_rep[64][9];
     double ekt_rep[64][9];
     unsigned long long npairs_rep[64][2];
+    // `refcoord_scaling = com`: plain average of the restraint reference positions, scaled with the box, and its value
+    // before the last coupling step (the scaling kernel shifts every reference by the difference)
+    double posres_com[3], posres_com_old[3];
     long long ts_min[24], ts_max[24];   // diagnostic build (-DMDX_STAMPS): first start and last end of each kernel, 100 MHz clock
 };
 #define MDX_NREP 64

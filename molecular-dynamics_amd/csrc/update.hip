@@ -411,6 +411,7 @@ __global__ void k_pcouple(DevState *dw, int kind, double tau_p, double ref_p, do
         dw->pr_M[0] = dw->pr_M[4] = dw->pr_M[8] = 2.0 * rate;
     }
     for (int a = 0; a < 9; a++) dw->mu[a] = mu[a];
+    for (int a = 0; a < 3; a++) { dw->posres_com_old[a] = dw->posres_com[a]; dw->posres_com[a] *= mu[0]; }
     // new box (rows scaled isotropically)
     for (int a = 0; a < 9; a++) b[a] *= mu[0];
     DevBox nb;
@@ -425,8 +426,10 @@ __global__ void k_pcouple(DevState *dw, int kind, double tau_p, double ref_p, do
 }
 
 // Scale coordinates (and restraint references) by mu; C-rescale also scales velocities by 1/mu.
+// refcoord_scaling 1 (`all`, /root/reference/mdp/npt_complex.mdp:72) scales every reference position, 2 (`com`,
+// /root/reference/mdp/npt.mdp:40) moves them rigidly with their scaled centre.
 __global__ void k_scale(int n, float4 *__restrict__ x, float4 *__restrict__ v, const DevState *__restrict__ d, int scale_v,
-                        int nposres, float4 *__restrict__ posres_ref)
+                        int nposres, float4 *__restrict__ posres_ref, int refcoord_scaling)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const float m = (float)d->mu[0];
@@ -434,7 +437,16 @@ __global__ void k_scale(int n, float4 *__restrict__ x, float4 *__restrict__ v, c
         float4 p = x[i]; p.x *= m; p.y *= m; p.z *= m; x[i] = p;
         if (scale_v) { float4 w = v[i]; const float im = 1.0f / m; w.x *= im; w.y *= im; w.z *= im; v[i] = w; }
     }
-    if (i < nposres) { float4 r = posres_ref[i]; r.x *= m; r.y *= m; r.z *= m; posres_ref[i] = r; }
+    if (i < nposres) {
+        float4 r = posres_ref[i];
+        if (refcoord_scaling == 1) { r.x *= m; r.y *= m; r.z *= m; }
+        else {
+            r.x += (float)(d->posres_com[0] - d->posres_com_old[0]);
+            r.y += (float)(d->posres_com[1] - d->posres_com_old[1]);
+            r.z += (float)(d->posres_com[2] - d->posres_com_old[2]);
+        }
+        posres_ref[i] = r;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_comm_sum(int n, const float4 *__restrict__ v, DevState *dw)
@@ -580,7 +592,7 @@ int mdx_launch_pcouple(mdx_system *s)
                        (double)s->nstpcouple * s->dt, kT, (unsigned long long)s->seed, s->step);
     const int nb = (std::max(s->n, s->nposres) + 255) / 256;
     hipLaunchKernelGGL(k_scale, dim3(nb), dim3(256), 0, s->stream, s->n, s->x, s->v, s->d, s->pcoupl == 1 ? 1 : 0,
-                       s->refcoord_scaling ? s->nposres : 0, s->posres_ref);
+                       s->refcoord_scaling ? s->nposres : 0, s->posres_ref, s->refcoord_scaling);
     MDX_CHECK(s, hipGetLastError());
     return MDX_OK;
 }

@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmdx.so")
 
 SYMBOLS = [
     "mdx_version", "mdx_last_error", "mdx_create", "mdx_destroy", "mdx_set_atoms", "mdx_set_exclusions",
-    "mdx_set_bonds", "mdx_set_angles", "mdx_set_dihedrals", "mdx_set_pairs14", "mdx_set_posres", "mdx_set_settles",
+    "mdx_set_bonds", "mdx_set_angles", "mdx_set_dihedrals", "mdx_set_pairs14", "mdx_set_posres", "mdx_get_posres_ref", "mdx_set_settles",
     "mdx_set_constraints", "mdx_set_nonbonded", "mdx_set_pme", "mdx_set_integrator", "mdx_set_tcoupl",
     "mdx_set_pcoupl", "mdx_set_dispcorr", "mdx_set_pull", "mdx_set_state", "mdx_set_state_device", "mdx_get_state",
     "mdx_get_step", "mdx_compute_forces", "mdx_get_forces", "mdx_get_energies", "mdx_get_virial", "mdx_step",
@@ -65,6 +65,7 @@ def load_library(path: str | None = None):
     L.mdx_set_dihedrals.argtypes = [vp, c_int, ip, fp, fp, ip]
     L.mdx_set_pairs14.argtypes = [vp, c_int, ip, fp, fp, fp]
     L.mdx_set_posres.argtypes = [vp, c_int, ip, fp, fp, c_int]
+    L.mdx_get_posres_ref.argtypes = [vp, fp]
     L.mdx_set_settles.argtypes = [vp, c_int, ip, c_f, c_f]
     L.mdx_set_constraints.argtypes = [vp, c_int, ip, fp, c_int, c_int]
     L.mdx_set_nonbonded.argtypes = [vp, c_f, c_f, c_f, c_int]
@@ -377,6 +378,12 @@ class Engine:
         x = np.zeros((self.n, 3), np.float32); v = np.zeros((self.n, 3), np.float32); box = np.zeros(9, np.float32)
         self._call("mdx_get_state", _p(x, ctypes.c_float), _p(v, ctypes.c_float), _p(box, ctypes.c_float))
         return x, v, box.reshape(3, 3)
+
+    def posres_ref(self):
+        """Restraint reference positions as pressure coupling has moved them (`refcoord_scaling`)."""
+        r = np.zeros((len(self.sys.posres_idx), 3), np.float32)
+        self._call("mdx_get_posres_ref", _p(r, ctypes.c_float))
+        return r
 
     def set_pull(self, group1, group2, type="constant-force", k=500.0, rate=0.0, init=0.0, start=True,
                  dim=(1, 1, 1), nstout=50, pbcatom1=-1, pbcatom2=-1):

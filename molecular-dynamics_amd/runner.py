@@ -400,6 +400,13 @@ def mdrun(argv, out=sys.stdout, err=sys.stderr) -> int:
         if len(cp["x"]) != sysm.natoms:
             err.write(f"Fatal error:\ncheckpoint {cpi} has {len(cp['x'])} atoms, the run input {sysm.natoms}\n")
             return 1
+        # restraint references are fractional in the run input's box (`refcoord_scaling`): carry them into the
+        # checkpoint's box the way pressure coupling has moved them since
+        mode = m.s("refcoord_scaling").lower()
+        if meta.get("use_posres") and len(sysm.posres_idx) and mode != "no":
+            carry = np.linalg.solve(np.asarray(sysm.box, float), np.asarray(cp["box"], float))
+            ref = np.asarray(sysm.posres_ref, float)
+            sysm.posres_ref = ref @ carry if mode == "all" else ref + (ref.mean(0) @ carry - ref.mean(0))
         sysm.x, sysm.v, sysm.box = cp["x"], cp["v"], cp["box"]
         step0 = int(cp["step"])
         appending = a.append

@@ -266,9 +266,12 @@ def pairs14(x, idx, c6, c12, qq):
     return elj.sum(), ec.sum(), f, vir
 
 
-def posres(x, box, idx, ref, k):
+def posres(x, box, idx, ref, k, refcoord_scaling="all"):
     """Position restraints V = 1/2 sum_d k_d (x_d - ref_d)^2 with minimum image
-    (`define = -DPOSRES`, /root/reference/mdp/nvt_complex.mdp:2)."""
+    (`define = -DPOSRES`, /root/reference/mdp/nvt_complex.mdp:2). The virial is the strain derivative with the
+    references following the box as `refcoord_scaling` says: all of each reference (`all`,
+    /root/reference/mdp/npt_complex.mdp:72), only the plain average of the references (`com`,
+    /root/reference/mdp/npt.mdp:40) or nothing (`no`)."""
     f = np.zeros_like(x)
     if len(idx) == 0:
         return 0.0, f, np.zeros((3, 3))
@@ -276,8 +279,18 @@ def posres(x, box, idx, ref, k):
     e = 0.5 * (k * d * d).sum()
     fs = -k * d
     np.add.at(f, idx, fs)
-    vir = -0.5 * np.einsum("na,nb->ab", d, fs)
+    arm = {"all": d, "com": d + ref - ref.mean(0), "no": d + ref}[refcoord_scaling]
+    vir = -0.5 * np.einsum("na,nb->ab", arm, fs)
     return e, f, vir
+
+
+def scale_posres_ref(ref, mu, refcoord_scaling):
+    """Reference positions after the box was scaled isotropically by mu about the origin."""
+    if refcoord_scaling == "all":
+        return ref * mu
+    if refcoord_scaling == "com":
+        return ref + (mu - 1.0) * ref.mean(0)
+    return ref.copy()
 
 
 def dispersion_correction(sigma, eps, box, rc, excl_start=None):

@@ -123,6 +123,36 @@ def test_pressure_coupling_relaxes_density(equilibrated_water, kind):
     assert abs(P[100:].mean() - 1.0) < 0.5 * P[100:].std() + 150
 
 
+@pytest.mark.parametrize("mode", ["no", "all", "com"])
+def test_refcoord_scaling_modes(small_complex, mode):
+    """`refcoord_scaling` (/root/reference/mdp/npt_complex.mdp:72 `all`, /root/reference/mdp/npt.mdp:40 `com`): the
+    restraint virial of the starting configuration against the oracle, then 40 steps of C-rescale with an exaggerated
+    compressibility; the references must have followed the box as the oracle's rule says."""
+    s = small_complex
+    code = {"no": 0, "all": 1, "com": 2}[mode]
+    e = eng.Engine(s, rc=1.0, dt=0.001, nstcalcenergy=10, tc_groups=["System"], ref_t=[300.0], tau_t=[0.1], use_posres=True,
+                   refcoord_scaling=code, pcoupl=1, tau_p=0.5, ref_p=1.0, compressibility=2e-3, nstpcouple=10)
+    ref0 = s.posres_ref.astype(np.float32).astype(np.float64)
+    rng = np.random.default_rng(11)
+    x = (s.x + rng.normal(scale=0.004, size=s.x.shape)).astype(np.float32).astype(np.float64)
+    e.set_state(x, s.v, s.box)
+    e.compute(eng.F_POSRES)
+    v, _ = e.virial()
+    vo = R.posres(x, s.box, s.posres_idx, ref0, s.posres_k, refcoord_scaling=mode)[2]
+    assert np.abs(v - vo).max() < 1e-4 * np.abs(vo).max()
+    assert np.abs(e.posres_ref() - ref0).max() == 0.0
+    e.set_state(s.x, s.v, s.box)
+    e.step(41)
+    _, _, box = e.get_state()
+    got = e.posres_ref().astype(np.float64); e.close()
+    mu = float(box[0, 0]) / float(np.float32(s.box[0, 0]))
+    assert abs(mu - 1.0) > 1e-4            # the box did move
+    want = R.scale_posres_ref(ref0, mu, mode)
+    assert np.abs(got - want).max() < 2e-5
+    if mode != "no":
+        assert np.abs(got - ref0).max() > 1e-4
+
+
 def test_constant_force_pull(small_complex):
     """`pull_coord1_type = constant-force`, k = 500, start = yes
     (/root/reference/mdp/pull_short.mdp:41-46): the force column is -k and the COM distance

@@ -146,6 +146,24 @@ def test_bonded_forces_are_gradients(small_complex):
     _fd_check(lambda y: R.posres(y, s.box, s.posres_idx, s.posres_ref, s.posres_k)[:2], x, atoms)
 
 
+@pytest.mark.parametrize("mode", ["all", "com", "no"])
+def test_posres_virial_is_strain_derivative(small_complex, mode):
+    """dE/d(eps) under x -> (1+eps) x with the references following as `refcoord_scaling` says equals 2 tr(virial)."""
+    s = small_complex
+    rng = np.random.default_rng(3)
+    x = s.x + rng.normal(scale=0.01, size=s.x.shape)
+    ref = s.posres_ref
+
+    def energy(eps):
+        return R.posres(x * (1 + eps), s.box * (1 + eps), s.posres_idx, R.scale_posres_ref(ref, 1 + eps, mode), s.posres_k)[0]
+    h = 1e-6
+    de = (energy(h) - energy(-h)) / (2 * h)
+    vir = R.posres(x, s.box, s.posres_idx, ref, s.posres_k, refcoord_scaling=mode)[2]
+    assert abs(de - 2 * np.trace(vir)) < 1e-6 * max(1.0, abs(de))
+    if mode != "all":
+        assert abs(np.trace(vir) - np.trace(R.posres(x, s.box, s.posres_idx, ref, s.posres_k)[2])) > 1e-3
+
+
 def test_dihedral_angle_convention():
     # cis = 0, trans = 180 degrees (IUPAC), right-handed sign
     x = np.array([[1.0, 1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 0.0], [0.0, 1.0, 0.0]])
