@@ -280,8 +280,10 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                 fjx -= fx; fjy -= fy; fjz -= fz;
                 if (ENERGY) {
                     if (within && listed) {
-                        npair++;
-                        if (e4 != 0.0f) nlj++;
+                        if (hs_c >= 0.0f && lj.x >= 0.0f) {         // statistics count pairs of real atoms, not fillers
+                            npair++;
+                            if (e4 != 0.0f) nlj++;
+                        }
                         const float c2 = sg * sg * (1.0f / rc2);
                         const float c6 = c2 * c2 * c2;
                         elj += t6 * (s6 - 1.0f) - e4 * c6 * (c6 - 1.0f);

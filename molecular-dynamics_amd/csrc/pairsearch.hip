@@ -168,7 +168,8 @@ __global__ __launch_bounds__(1024) void k_sortcol(const int *__restrict__ col_co
         const float4 w = wrapped[as];
         const float q = filler ? 0.0f : x[as].w;
         xq_s[g] = make_float4(w.x, w.y, w.z, q);
-        lj_s[g] = filler ? make_float2(0.0f, 0.0f) : lj[as];
+        // a filler carries no charge and no LJ well; the negative sign of its (negligible) half-sigma marks it for the pair counters
+        lj_s[g] = filler ? make_float2(-1.0e-30f, 0.0f) : lj[as];
         perm[g] = filler ? -1 : a;
         perm_src[g] = as;
         shift_s[g] = __float_as_int(w.w);
