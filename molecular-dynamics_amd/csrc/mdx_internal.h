@@ -186,6 +186,7 @@ struct mdx_system {
     int npairs = 0; int2 *pair_ij = nullptr; float4 *pair_p = nullptr;
     int nposres = 0; int *posres_idx = nullptr; float4 *posres_ref = nullptr; float4 *posres_k = nullptr;
     int refcoord_scaling = 0;     // 0 no, 1 all, 2 com
+    int perm_n = -1;              // atom count the cluster order in `perm` was built for (-1: none yet)
     // constraints
     int nsettle_cap = 0;          // settles set up (domain decomposition activates the first nsettle of them)
     int nsettle = 0; int4 *settle_idx = nullptr; float settle_doh = 0, settle_dhh = 0;

@@ -17,12 +17,22 @@
 #define BIG_KEY 3.0e38f
 
 
+// `order` (or null): the cluster order of the previous search over the same n atoms. Atoms move a fraction of a
+// column during a list lifetime, so threads that walk the atoms in that order find a wave's 64 atoms in one or two
+// columns and the loop of returning atomics below runs once or twice instead of once per column a wave of atoms in
+// input order touches. Skipped when that search overflowed a capacity (its order may then be incomplete).
 __global__ void k_bin(int n, const float4 *__restrict__ x, const DevState *__restrict__ d, int ncx, int ncy,
                       int *__restrict__ col_count, float4 *__restrict__ wrapped, int *__restrict__ atom_col,
-                      int *__restrict__ atom_slot)
+                      int *__restrict__ atom_slot, const int *__restrict__ order)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < n;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = g;
+    bool live = g < n;
+    if (order && d->overflow == 0 && d->nsc > 0) {
+        i = g < d->nsc * 64 ? order[g] : -1;
+        live = i >= 0 && i < n;
+        if (!live) i = 0;
+    }
     const float *h = d->box.h;
     float4 p = live ? x[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     int nc = (int)floorf(p.z / h[8]);
@@ -630,8 +640,11 @@ int mdx_search(mdx_system *s)
     const int ncol = ncx * ncy;
     MDX_CHECK(s, hipMemsetAsync(s->col_count, 0, sizeof(int) * (ncol + 1), s->stream));
     const int nbk = (s->n + 255) / 256;
-    hipLaunchKernelGGL(k_bin, dim3(nbk), dim3(256), 0, s->stream, s->n, s->x, s->d, ncx, ncy, s->col_count, s->wrapped,
-                       s->atom_col, s->atom_slot);
+    const bool reuse_order = s->perm_n == s->n && !(s->dbg & 0x8000000);
+    hipLaunchKernelGGL(k_bin, dim3(reuse_order ? (std::max(s->n, s->npad) + 255) / 256 : nbk), dim3(256), 0, s->stream, s->n, s->x,
+                       s->d, ncx, ncy, s->col_count, s->wrapped, s->atom_col, s->atom_slot,
+                       (const int *)(reuse_order ? s->perm : nullptr));
+    s->perm_n = s->n;
     hipLaunchKernelGGL(k_colscan, dim3(1), dim3(1024), 0, s->stream, ncol, s->col_count, s->col_astart, s->col_scstart,
                        s->d, s->npad / 64);
     hipLaunchKernelGGL(k_fill, dim3(nbk), dim3(256), 0, s->stream, s->n, s->atom_col, s->atom_slot, s->col_astart, s->col_atoms);
