@@ -104,11 +104,14 @@ __global__ void k_fill(int n, const int *__restrict__ atom_col, const int *__res
 }
 
 // Bitonic sort of aligned blocks of B (power of two) elements by key k[], ascending; carries
-// three companion arrays. All threads of the block must call.
+// three companion arrays. All threads of the block must call. The workgroup size is a multiple of 64, so element t
+// and its partner t ^ j belong to the same wave whenever j < 64: a compare-exchange step with such a j, followed by
+// another one, needs the wave's own LDS traffic ordered and no workgroup barrier (70 of the 80 steps of a column).
 __device__ void bitonic_blocks(float *k, float *c1, float *c2, int *id, int P, int B)
 {
     for (int kk = 2; kk <= B; kk <<= 1) {
         for (int j = kk >> 1; j > 0; j >>= 1) {
+            const int jnext = j > 1 ? (j >> 1) : kk;        // partner distance of the step that follows (if any)
             for (int t = threadIdx.x; t < P; t += blockDim.x) {
                 const int u = t ^ j;
                 if (u > t) {
@@ -124,9 +127,15 @@ __device__ void bitonic_blocks(float *k, float *c1, float *c2, int *id, int P, i
                     }
                 }
             }
-            __syncthreads();
+            if (j >= 64 || jnext >= 64) __syncthreads();
+            else {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
         }
     }
+    __syncthreads();
 }
 
 __global__ __launch_bounds__(1024) void k_sortcol(const int *__restrict__ col_count, const int *__restrict__ col_astart,
