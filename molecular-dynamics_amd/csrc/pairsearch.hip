@@ -65,28 +65,48 @@ __global__ void k_bin(int n, const float4 *__restrict__ x, const DevState *__res
     atom_slot[i] = slot;
 }
 
-// One block: exclusive prefix sums of column atom counts and of column super-cluster counts.
-__global__ void k_colscan(int ncol, const int *__restrict__ col_count, int *__restrict__ col_astart,
-                          int *__restrict__ col_scstart, DevState *__restrict__ d, int nsc_cap)
+// One block of 1024: exclusive prefix sums of column atom counts and of column super-cluster counts (wave scans with
+// lane shifts, the sixteen wave totals scanned by the first wave), the list counters reset, and the lattice shift
+// vectors of the current box (MDX_MAX_SHIFTS <= 1024).
+__global__ __launch_bounds__(1024) void k_colscan(int ncol, const int *__restrict__ col_count, int *__restrict__ col_astart,
+                                                  int *__restrict__ col_scstart, DevState *__restrict__ d, int nsc_cap,
+                                                  int nshift, const int3 *__restrict__ shift_ijk, float4 *__restrict__ shiftvec)
 {
-    __shared__ int sa[1024], ss[1024];
-    const int t = threadIdx.x;
+    __shared__ int wa[16], ws[16];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int per = (ncol + blockDim.x - 1) / blockDim.x;
     const int b = t * per, e = min(ncol, b + per);
     int a = 0, s = 0;
     for (int c = b; c < e; c++) { a += col_count[c]; s += (col_count[c] + 63) >> 6; }
-    sa[t] = a; ss[t] = s;
+    int ia = a, is = s;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int va = __shfl_up(ia, o, 64), vs = __shfl_up(is, o, 64);
+        if (lane >= o) { ia += va; is += vs; }
+    }
+    if (lane == 63) { wa[w] = ia; ws[w] = is; }
     __syncthreads();
-    if (t == 0) {
-        int ra = 0, rs = 0;
-        for (int k = 0; k < (int)blockDim.x; k++) { int ta = sa[k], ts = ss[k]; sa[k] = ra; ss[k] = rs; ra += ta; rs += ts; }
-        col_astart[ncol] = ra; col_scstart[ncol] = rs;
-        d->nsc = rs; d->ncj = 0; d->nwork = 0; d->nexcl = 1; d->ntiles = 0;
-        if (rs > nsc_cap) d->overflow |= 16;
+    if (w == 0) {
+        const int oa = lane < 16 ? wa[lane] : 0, os = lane < 16 ? ws[lane] : 0;
+        int ta = oa, ts = os;
+        for (int o = 1; o < 16; o <<= 1) {
+            const int va = __shfl_up(ta, o, 64), vs = __shfl_up(ts, o, 64);
+            if (lane >= o) { ta += va; ts += vs; }
+        }
+        if (lane < 16) { wa[lane] = ta - oa; ws[lane] = ts - os; }
+        if (lane == 15) {
+            col_astart[ncol] = ta; col_scstart[ncol] = ts;
+            d->nsc = ts; d->ncj = 0; d->nwork = 0; d->nexcl = 1; d->ntiles = 0;
+            if (ts > nsc_cap) d->overflow |= 16;
+        }
     }
     if (t < 257) { d->cost_hist[t] = 0; d->cost_cursor[t] = 0; }
+    if (t < nshift) {
+        const float *h = d->box.h;
+        const int3 sh = shift_ijk[t];
+        shiftvec[t] = make_float4(sh.x * h[0] + sh.y * h[3] + sh.z * h[6], sh.y * h[4] + sh.z * h[7], sh.z * h[8], 0.0f);
+    }
     __syncthreads();
-    a = sa[t]; s = ss[t];
+    a = ia - a + wa[w]; s = is - s + ws[w];
     for (int c = b; c < e; c++) {
         col_astart[c] = a; col_scstart[c] = s;
         const int cnt = col_count[c];
@@ -576,17 +596,6 @@ __global__ void k_prepare(int npad, DevState *__restrict__ d, const float4 *__re
     f_s[3 * g] = 0.0f; f_s[3 * g + 1] = 0.0f; f_s[3 * g + 2] = 0.0f;
 }
 
-__global__ void k_shiftvec(const DevState *__restrict__ d, int nshift, const int3 *__restrict__ shift_ijk,
-                           float4 *__restrict__ shiftvec)
-{
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    const float *h = d->box.h;
-    if (g < nshift) {
-        const int3 s = shift_ijk[g];
-        shiftvec[g] = make_float4(s.x * h[0] + s.y * h[3] + s.z * h[6], s.y * h[4] + s.z * h[7], s.z * h[8], 0.0f);
-    }
-}
-
 // With `fork` the kernel's own completion signal is the fork event of the side streams (an event
 // recorded by a separate marker costs the main stream several microseconds between two kernels).
 int mdx_launch_prepare(mdx_system *s, bool fork)
@@ -655,13 +664,12 @@ int mdx_search(mdx_system *s)
                        (const int *)(reuse_order ? s->perm : nullptr));
     s->perm_n = s->n;
     hipLaunchKernelGGL(k_colscan, dim3(1), dim3(1024), 0, s->stream, ncol, s->col_count, s->col_astart, s->col_scstart,
-                       s->d, s->npad / 64);
+                       s->d, s->npad / 64, s->nshift, s->shift_ijk, s->shiftvec);
     hipLaunchKernelGGL(k_fill, dim3(nbk), dim3(256), 0, s->stream, s->n, s->atom_col, s->atom_slot, s->col_astart, s->col_atoms);
     hipLaunchKernelGGL(k_sortcol, dim3(ncol), dim3(1024), 0, s->stream, s->col_count, s->col_astart, s->col_scstart,
                        s->col_atoms, s->wrapped, s->x, s->lj, s->molid, s->xq_s, s->lj_s, s->perm, s->perm_src, s->shift_s,
                        s->molid_s, s->sorted_of, s->bb_lo, s->bb_hi, s->sbb_lo, s->sbb_hi, s->npad / 64,
                        (const float4 *)(s->dd_on ? s->v : nullptr));
-    hipLaunchKernelGGL(k_shiftvec, dim3(1), dim3(64), 0, s->stream, s->d, s->nshift, s->shift_ijk, s->shiftvec);
     ListArgs A;
     A.dro = s->d; A.d = s->d; A.ncx = ncx; A.ncy = ncy; A.col_scstart = s->col_scstart; A.xq_s = s->xq_s; A.perm = s->perm;
     A.molid_s = s->molid_s; A.bb_lo = s->bb_lo; A.bb_hi = s->bb_hi; A.sbb_lo = s->sbb_lo; A.sbb_hi = s->sbb_hi;
