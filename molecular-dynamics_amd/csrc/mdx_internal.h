@@ -163,7 +163,7 @@ struct mdx_system {
     int nshift = 0, central_shift = 0;
     int3 *shift_ijk = nullptr;    // device
     float4 *shiftvec = nullptr;   // device, refreshed each step from the box
-    std::vector<int3> h_shift_ijk;
+    std::vector<int3> h_shift_ijk, h_shift_sent;     // lattice shifts of the current box; the list last copied to the device
     // nonbonded parameters
     float rc = 1.0f, rlist = 1.1f, beta = 3.12341f;
     float4 *htab = nullptr;       // ... with h(w) = erf(z)/z beside g, for the energy kernel

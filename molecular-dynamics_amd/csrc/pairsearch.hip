@@ -13,6 +13,7 @@
 // MDX_NB_CHUNK entries for the nonbonded kernel.
 #include "mdx_internal.h"
 #include <hip/hip_ext.h>
+#include <cstring>
 
 #define BIG_KEY 3.0e38f
 
@@ -158,7 +159,7 @@ __device__ void bitonic_blocks(float *k, float *c1, float *c2, int *id, int P, i
     __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void k_sortcol(const int *__restrict__ col_count, const int *__restrict__ col_astart,
+__global__ __launch_bounds__(1024) void k_sortcol(int *__restrict__ col_count, const int *__restrict__ col_astart,
                                                  const int *__restrict__ col_scstart, const int *__restrict__ col_atoms,
                                                  const float4 *__restrict__ wrapped, const float4 *__restrict__ x,
                                                  const float2 *__restrict__ lj, const int *__restrict__ molid,
@@ -176,6 +177,9 @@ __global__ __launch_bounds__(1024) void k_sortcol(const int *__restrict__ col_co
     const int base = col_astart[col];
     const int nscol = (n + 63) >> 6;
     const int sc0 = col_scstart[col];
+    // the column counters are left at zero for the binning of the next search (this kernel is their last reader)
+    __syncthreads();
+    if (threadIdx.x == 0) col_count[col] = 0;
     if (sc0 + nscol > nsc_cap) return;
     int P = 64;
     while (P < nscol * 64) P <<= 1;
@@ -644,7 +648,12 @@ int mdx_search(mdx_system *s)
     const double *box = s->h->boxd;
     build_shift_list(s, box);
     if (s->nshift > MDX_MAX_SHIFTS) { s->err = "too many lattice shifts (box too small for rlist)"; return MDX_ERR_UNSUPPORTED; }
-    MDX_CHECK(s, hipMemcpyAsync(s->shift_ijk, s->h_shift_ijk.data(), sizeof(int3) * s->nshift, hipMemcpyHostToDevice, s->stream));
+    // the shift list changes only when the box shape does
+    if (s->h_shift_ijk.size() != s->h_shift_sent.size() ||
+        memcmp(s->h_shift_ijk.data(), s->h_shift_sent.data(), sizeof(int3) * s->h_shift_ijk.size()) != 0) {
+        s->h_shift_sent = s->h_shift_ijk;
+        MDX_CHECK(s, hipMemcpyAsync(s->shift_ijk, s->h_shift_sent.data(), sizeof(int3) * s->nshift, hipMemcpyHostToDevice, s->stream));
+    }
     // column grid: super-cluster cells roughly cubic
     const double vol = box[0] * box[4] * box[8];
     // (a decomposed domain fills part of the box only: its columns are sized by the density of the whole system)
@@ -656,7 +665,8 @@ int mdx_search(mdx_system *s)
     while (ncx * ncy > s->ncol_cap) { if (ncx >= ncy) ncx--; else ncy--; }
     s->ncx = ncx; s->ncy = ncy;
     const int ncol = ncx * ncy;
-    MDX_CHECK(s, hipMemsetAsync(s->col_count, 0, sizeof(int) * (ncol + 1), s->stream));
+    // k_sortcol zeroes the counters it has consumed: only the first search clears the array
+    if (s->perm_n < 0) MDX_CHECK(s, hipMemsetAsync(s->col_count, 0, sizeof(int) * (s->ncol_cap + 1), s->stream));
     const int nbk = (s->n + 255) / 256;
     const bool reuse_order = s->perm_n == s->n && !(s->dbg & 0x8000000);
     hipLaunchKernelGGL(k_bin, dim3(reuse_order ? (std::max(s->n, s->npad) + 255) / 256 : nbk), dim3(256), 0, s->stream, s->n, s->x,
