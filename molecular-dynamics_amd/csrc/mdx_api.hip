@@ -69,7 +69,8 @@ extern "C" mdx_system *mdx_create(int device, int natoms)
               hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_pme, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_bond, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
-              hipEventCreateWithFlags(&s->ev_spread, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
+              hipEventCreateWithFlags(&s->ev_spread, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
+              hipEventCreateWithFlags(&s->ev_nbdone, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
     const int n = natoms;
     // MDX_NB_DYN=0 in the environment selects the static deal of the nonbonded kernel (processes sharing one GPU)
     if (const char *e = getenv("MDX_NB_DYN")) s->nb_dyn = atoi(e);
@@ -130,6 +131,7 @@ extern "C" void mdx_destroy(mdx_system *s)
     if (s->ev_pme) (void)hipEventDestroy(s->ev_pme);
     if (s->ev_bond) (void)hipEventDestroy(s->ev_bond);
     if (s->ev_spread) (void)hipEventDestroy(s->ev_spread);
+    if (s->ev_nbdone) (void)hipEventDestroy(s->ev_nbdone);
     if (s->st_pme) (void)hipStreamDestroy(s->st_pme);
     if (s->st_bond) (void)hipStreamDestroy(s->st_bond);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -752,7 +754,18 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early)
         if (phase == 1) return MDX_OK;
     }
     if (phase == 2) if ((rc = mdx_launch_pme(s, need_vir, true))) return rc;
-    if ((rc = mdx_join(s))) return rc;
+    if (phase == 0 && s->rotate_streams && s->have_pme && !s->gather_on_main && !s->spread_on_main) {
+        // The PME chain ends about when the nonbonded kernel does. A stream that waits for an event of another one
+        // resumes several microseconds after it fires; the update is therefore enqueued behind the gather on the
+        // PME stream, which waits for the two other streams (mostly finished by then) and becomes the main stream
+        // of the next step, while this one takes the next PME chain.
+        MDX_CHECK(s, hipEventRecord(s->ev_nbdone, s->stream));
+        MDX_CHECK(s, hipEventRecord(s->ev_bond, s->st_bond));
+        MDX_CHECK(s, hipStreamWaitEvent(s->st_pme, s->ev_nbdone, 0));
+        MDX_CHECK(s, hipStreamWaitEvent(s->st_pme, s->ev_bond, 0));
+        s->pme_signalled = false;
+        std::swap(s->stream, s->st_pme);
+    } else if ((rc = mdx_join(s))) return rc;
     if ((rc = mdx_launch_update(s, tc_apply, s->pcoupl == 2, need_vir))) return rc;
     // The PME and bonded kernels of the next step read only the new positions (the spread goes through the
     // sort permutation): when that step neither rebuilds the list nor accumulates energies they are

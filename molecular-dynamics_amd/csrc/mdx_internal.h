@@ -111,6 +111,7 @@ struct mdx_system {
     int dbg = 0;                       // diagnostic ablation bits (mdx_debug_set key 2)
     int nb_dyn = 1;                    // nonbonded kernel: rounds' worth of cheap units scheduled dynamically (mdx_debug_set key 3)
     int nb_dyn_split = 0;              // ... in 2^nb_dyn_split parts per unit (mdx_debug_set key 4)
+    int rotate_streams = 0;            // the update follows the PME chain on its stream, which becomes the main stream of the next step (mdx_debug_set key 9)
     int gather_on_main = 0;            // PME gather behind the nonbonded kernel on the main stream: measured slower, the nonbonded kernel ends last (mdx_debug_set key 8)
     const float *gather_pending = nullptr;
     int spread_on_main = 0;            // charge spreading on the main stream ahead of the nonbonded kernel: measured slower (mdx_debug_set key 7)
@@ -121,7 +122,7 @@ struct mdx_system {
     hipStream_t stream = nullptr;      // main stream: search, nonbonded, update
     hipStream_t st_pme = nullptr;      // PME chain (spread, FFTs, solve, gather) overlaps the nonbonded kernel
     hipStream_t st_bond = nullptr;     // bonded, restraint, exclusion and pull kernels
-    hipEvent_t ev_fork = nullptr, ev_pme = nullptr, ev_bond = nullptr, ev_spread = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_pme = nullptr, ev_bond = nullptr, ev_spread = nullptr, ev_nbdone = nullptr;
     float *f_pme = nullptr;            // 3N mesh forces (plain stores, so no race with the atomics on f)
     std::string err;
     int n = 0;                    // atoms

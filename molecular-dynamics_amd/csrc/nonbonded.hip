@@ -554,6 +554,7 @@ extern "C" int mdx_debug_set(mdx_system *s, int key, int value)
     if (key == 2) { s->dbg = value; return MDX_OK; }
     if (key == 3) { s->nb_dyn = value; return MDX_OK; }
     if (key == 8) { s->gather_on_main = value; return MDX_OK; }
+    if (key == 9) { s->rotate_streams = value; return MDX_OK; }
     if (key == 7) { s->spread_on_main = value; return MDX_OK; }
     if (key == 6) { s->bond_on_main = value; return MDX_OK; }
     if (key == 5) { s->early_fork = value; return MDX_OK; }

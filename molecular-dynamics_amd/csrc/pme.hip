@@ -728,6 +728,7 @@ int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done)
         s->grid_clean = true;
         potential = s->phi;
     } else {
+    hipfftSetStream(s->plan_r2c, s->st_pme); hipfftSetStream(s->plan_c2r, s->st_pme);     // the streams may have changed roles
     if (hipfftExecR2C(s->plan_r2c, s->grid, (hipfftComplex *)s->cgrid) != HIPFFT_SUCCESS) { s->err = "hipfftExecR2C failed"; return MDX_ERR_HIP; }
     const int nbs = (int)((ncx + 255) / 256);
     if (energy)
