@@ -74,3 +74,23 @@ def test_argument_errors_are_reported_not_executed():
         assert e.get_step() == 3
     finally:
         e.close()
+
+
+def test_search_after_the_state_was_replaced():
+    """The pair search walks the atoms in the cluster order of the previous search; that order says nothing about a state
+    set afterwards (here: every molecule moved to another molecule's place) and must not matter for the result."""
+    s = synth.water_box(box=np.diag([3.0, 3.0, 3.0]))
+    s.x = s.x.astype(np.float32).astype(np.float64)
+    e = eng.Engine(s, rc=1.0, nstcalcenergy=1)
+    try:
+        e.compute(eng.F_NONBONDED)
+        nw = s.natoms // 3
+        p = np.random.default_rng(5).permutation(nw)
+        x2 = s.x.reshape(nw, 3, 3)[p].reshape(-1, 3)
+        e.set_state(x2, s.v, s.box)
+        f, en = e.compute(eng.F_NONBONDED | eng.F_EXCL)
+        o = R.nonbonded(x2, s.charge, s.sigma, s.eps, s.box, 1.0, e.beta, s.excl_start, s.excl_list, flags=3, nthreads=4)
+        assert relrms(f, o["f"]) < 1e-5
+        assert e.list_stats()["pairs_within_rc"] == o["npairs"]
+    finally:
+        e.close()
