@@ -94,7 +94,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
     const int wpb = blockDim.x >> 6;          // waves per workgroup
     const int nwaves = gridDim.x * wpb;
     float elj = 0.0f, ecoul = 0.0f, eexcl = 0.0f;
-    unsigned int npair = 0, nlj = 0;
+    unsigned int npair = 0, nlj = 0;           // wave-uniform: lane masks counted on the scalar unit
     const bool do_pairs = A.do_pairs != 0, do_excl = A.do_excl != 0;
     float vxx = 0.0f, vxy = 0.0f, vxz = 0.0f, vyy = 0.0f, vyz = 0.0f, vzz = 0.0f;
     const float rc2 = A.rc2, beta = A.beta;
@@ -279,11 +279,13 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                 fix[c] += fx; fiy[c] += fy; fiz[c] += fz;
                 fjx -= fx; fjy -= fy; fjz -= fz;
                 if (ENERGY) {
+                    {
+                        // statistics: pairs of real atoms (a filler carries a negative half-sigma) inside the cutoff
+                        const bool counted = within && listed && hs_c >= 0.0f && lj.x >= 0.0f;
+                        npair += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(counted));
+                        nlj += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(counted && e4 != 0.0f));
+                    }
                     if (within && listed) {
-                        if (hs_c >= 0.0f && lj.x >= 0.0f) {         // statistics count pairs of real atoms, not fillers
-                            npair++;
-                            if (e4 != 0.0f) nlj++;
-                        }
                         const float c2 = sg * sg * (1.0f / rc2);
                         const float c6 = c2 * c2 * c2;
                         elj += t6 * (s6 - 1.0f) - e4 * c6 * (c6 - 1.0f);
@@ -354,9 +356,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
         elj = wave_sum(elj); ecoul = wave_sum(ecoul); eexcl = wave_sum(eexcl);
         vxx = wave_sum(vxx); vxy = wave_sum(vxy); vxz = wave_sum(vxz);
         vyy = wave_sum(vyy); vyz = wave_sum(vyz); vzz = wave_sum(vzz);
-        unsigned long long np64 = npair, nl64 = nlj;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { np64 += __shfl_xor(np64, o, 64); nl64 += __shfl_xor(nl64, o, 64); }
+        const unsigned long long np64 = npair, nl64 = nlj;
         if (lane == 0) {
             // replicated accumulators (folded by the finishing kernel): one replica per wave index mod 64
             const int rep = wave_id & (MDX_NREP - 1);
