@@ -121,6 +121,27 @@ def run_dd(args, rank, world, local):
         dist.destroy_process_group()
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks as children (one process per GPU,
+    rendezvous on 127.0.0.1) before this process makes any GPU call, pass their output through and exit with their
+    status. Counting devices does not initialise the GPU."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d needs %d GPUs, %d visible on this machine\n" % (args.gpus, args.gpus, have))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,11 +161,18 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="diagnostic with --no-output: steps per mdx_step call")
     ap.add_argument("--ring", type=int, default=8, help="pinned trajectory-frame slots between the GPU and the encoder threads")
     ap.add_argument("--encoders", type=int, default=3, help="host threads compressing trajectory frames")
+    ap.add_argument("--prime-steps", type=int, default=40,
+                    help="un-timed steps before the warmup that run every kernel variant, one pair search, the coupling steps and the "
+                         "frame pipeline once (first launches and first frames carry one-off costs of milliseconds)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not (args.gpus == 1 and world == 1):
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
@@ -168,12 +196,9 @@ def main():
     for kv in filter(None, os.environ.get("MDX_DEBUG", "").split(",")):     # diagnostic switches "key=value,..."
         e.debug_set(int(kv.split("=")[0]), int(kv.split("=")[1], 0))
     dt = e.dt
-    # ---- warmup
-    e.step(args.warmup); e.synchronize()
-    e.pop_energy_frames()
-    # ---- mdp-mandated output inside the timed region: compressed frames of the whole system every
-    # nstxout-compressed steps (/root/reference/mdp/production.mdp:12-13, pull_short.mdp:8), written
-    # by encoder threads while the step loop keeps the GPU queue filled
+    # ---- mdp-mandated output: compressed frames of the whole system every nstxout-compressed steps
+    # (/root/reference/mdp/production.mdp:12-13, pull_short.mdp:8), written by encoder threads while the step loop
+    # keeps the GPU queue filled
     nst_xtc = 0 if args.no_output else (10 if args.workload == "production" else 500)
     pipe = xtc = None
     xtc_path = None
@@ -185,33 +210,54 @@ def main():
         xtc = traj.XtcWriter(xtc_path, s.natoms, precision=1000.0)
         e.frame_ring(args.ring)
         pipe = FramePipeline(e, args.ring, xtc, None, None, dt, 0.0, nthreads=args.encoders)
-    e.enable_kernel_timing(True)
+
+    def run_steps(nsteps):
+        """The production loop: a frame whenever the step counter hits the cadence, steps in between."""
+        if nst_xtc:
+            done = 0
+            while done < nsteps:
+                if (e.get_step() % nst_xtc) == 0:
+                    slot = pipe.acquire_slot()
+                    e.capture_frame(slot)
+                    pipe.submit(slot, True, False, False)
+                n = min(nsteps - done, nst_xtc - e.get_step() % nst_xtc)
+                e.step(n)
+                done += n
+        elif args.chunk > 0:      # diagnostic: the call pattern of the output loop without the output
+            for _ in range(nsteps // args.chunk):
+                e.step(args.chunk)
+        else:
+            e.step(nsteps)
+
+    # ---- priming (not timed, before the warmup): every kernel variant of the step (plain, energy, coupling, search),
+    # the frame ring's first copies and the encoder threads' first frames carry one-off costs
+    if args.prime_steps > 0:
+        run_steps(args.prime_steps); e.synchronize()
+        if pipe is not None:
+            pipe.wait_idle()
+            xtc.f.seek(0); xtc.f.truncate(); xtc.frames = 0
+    # ---- warmup
+    e.step(args.warmup); e.synchronize()
+    e.pop_energy_frames()
+    e.enable_kernel_timing(True, stride=1 if args.steps <= 500 else 7)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
-    if nst_xtc:
-        done = 0
-        while done < args.steps:
-            if (e.get_step() % nst_xtc) == 0:
-                slot = pipe.acquire_slot()
-                e.capture_frame(slot)
-                pipe.submit(slot, True, False, False)
-            n = min(args.steps - done, nst_xtc - e.get_step() % nst_xtc)
-            e.step(n)
-            done += n
-    elif args.chunk > 0:      # diagnostic: the call pattern of the output loop without the output
-        for _ in range(args.steps // args.chunk):
-            e.step(args.chunk)
-    else:
-        e.step(args.steps)
+    run_steps(args.steps)
+    t_enq = time.perf_counter()
     e.synchronize(); torch.cuda.synchronize()
+    t_gpu = time.perf_counter()
     if pipe is not None:
         pipe.finish()
         xtc.close()
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    # where the wall time of the timed region went on this rank: enqueueing the steps (the host runs ahead of the GPU),
+    # the GPU finishing what was enqueued, the encoder threads finishing the frames still in flight
+    phases = {"enqueue_ms": round((t_enq - t0) * 1e3, 3), "gpu_drain_ms": round((t_gpu - t_enq) * 1e3, 3),
+              "output_drain_ms": round((time.perf_counter() - t_gpu) * 1e3, 3)}
     xtc_frames = xtc.frames if xtc is not None else 0
     xtc_bytes = os.path.getsize(xtc_path) if xtc_path else 0
     if pipe is not None and pipe.error is not None:
@@ -256,8 +302,8 @@ def main():
             "metric": "ns/day", "value": round(ns_day, 3), "unit": "ns/day", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 5), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("pseudo-complex S2 (%d atoms, dodecahedron d=%.1f nm), production.mdp settings, "
-                                    "%s barostat, energies every 10 steps, %s" % (
+            "config": {"workload": ("pseudo-complex S2 (%d atoms, dodecahedron d=%.1f nm), production.mdp settings with "
+                                    "pcoupl = %s, energies every 10 steps, %s" % (
                                         s.natoms, args.box, args.pcoupl,
                                         "xtc frame of the whole system every 10 steps compressed and written" if nst_xtc
                                         else "NO trajectory output (diagnostic run)"))
@@ -277,6 +323,7 @@ def main():
                          "flops_per_launch": flops, "pairs_within_rc": n_rc, "pairs_with_lj": n_lj,
                          "avg_launch_ms": round(nb_avg_s * 1e3, 5), "launches": nb_launches,
                          "evaluated_pair_lanes": stats["cluster_pairs"] * 64},
+            "timed_region": phases,
             "final": {"T": float(frames[-1, 2 + eng.E["TEMP"]]) if len(frames) else None,
                       "P_bar": float(frames[-1, 2 + eng.E["PRES"]]) if len(frames) else None,
                       "Epot": float(frames[-1, 2 + eng.E["POT"]]) if len(frames) else None,
@@ -322,4 +369,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -150,6 +150,31 @@ long long mdx_get_step(const mdx_system *sys);
  * counter-based random streams (`gmx mdrun -cpi`,
  * /root/reference/scripts/run_smd_with_recovery.py:149-156). */
 int mdx_set_step(mdx_system *sys, long long step);
+/* Run state beside x, v and box: the scalars that stochastic coupling, Parrinello-Rahman and the pull code carry
+ * from step to step on the device. A checkpoint written for `gmx mdrun -cpi`
+ * (/root/reference/scripts/run_smd_with_recovery.py:144-156; stage chaining with `grompp -t`,
+ * /root/reference/Snakefile:738,994) stores these MDX_RS_N doubles; mdx_set_run_state (after mdx_set_state,
+ * mdx_set_step and mdx_set_pull) makes the continuation use the scaling factors, box velocity, pull reference and
+ * work integral of the interrupted run instead of re-seeding them. EKINH, EKINH_OLD, MU and COM_V are read-only
+ * (the half-step kinetic energies per T-group, the last coupling step's scaling matrix and the last centre-of-mass
+ * momentum sum px, py, pz, mass). */
+enum {
+    MDX_RS_LAMBDA = 0,            /* 8: V-rescale factor per T-group for the coming coupling step */
+    MDX_RS_THERM_INTEGRAL = 8,    /* 8: thermostat work per T-group */
+    MDX_RS_EKINH = 16,            /* 8 */
+    MDX_RS_EKINH_OLD = 24,        /* 8 */
+    MDX_RS_PR_BOXV = 32,          /* 9: Parrinello-Rahman box velocity, nm/ps */
+    MDX_RS_MU = 41,               /* 9 */
+    MDX_RS_BARO_INTEGRAL = 50,
+    MDX_RS_PULL_INIT = 51,        /* umbrella reference at t = 0 (init + initial distance with start = yes) */
+    MDX_RS_PULL_WORK = 52,
+    MDX_RS_PULL_VALUE = 53,
+    MDX_RS_PULL_HAVE_INIT = 54,
+    MDX_RS_COM_V = 55,            /* 4 */
+    MDX_RS_N = 64
+};
+int mdx_get_run_state(mdx_system *sys, double *rs);
+int mdx_set_run_state(mdx_system *sys, const double *rs);
 /* `gen_vel = yes`, `gen_temp`, `gen_seed` (/root/reference/mdp/nvt_complex.mdp:39-41):
  * Maxwell-Boltzmann velocities, centre-of-mass motion removed, scaled to exactly `temperature`
  * over 3N degrees of freedom. */
@@ -221,7 +246,8 @@ int mdx_dd_step_end(mdx_system *sys);
 int mdx_dd_grid(mdx_system *sys, void **grid_dev, long long *nelem);
 int mdx_dd_stream_sync(mdx_system *sys);
 int mdx_dd_state_pointers(mdx_system *sys, void **x4_dev, void **v4_dev);
-/* Time the nonbonded kernel with HIP events on the handle's stream (bench only). */
+/* Time the nonbonded kernel with HIP events on the handle's stream (bench only): on = n > 0 samples every n-th
+ * force-only launch (a stride such as 7 does not lock onto the 10- and 20-step cadences of energy and search steps). */
 int mdx_enable_kernel_timing(mdx_system *sys, int on);
 int mdx_get_kernel_timing(mdx_system *sys, double *nb_ms_total, long long *nb_launches);
 /* Diagnostics (no counterpart in the reference): time `iters` back-to-back launches of the

@@ -578,6 +578,52 @@ extern "C" int mdx_get_state(mdx_system *s, float *x, float *v, float *box9)
 
 extern "C" long long mdx_get_step(const mdx_system *s) { return s->step; }
 
+// Run state: the coupling and pull scalars that live on the device between steps (layout: MDX_RS_* in mdx.h).
+extern "C" int mdx_get_run_state(mdx_system *s, double *rs)
+{
+    (void)hipSetDevice(s->device);
+    ARG_CHECK(s, rs, "mdx_get_run_state: null pointer");
+    int rc = sync_and_check(s); if (rc) return rc;
+    const DevState *h = s->h;
+    for (int k = 0; k < MDX_RS_N; k++) rs[k] = 0.0;
+    for (int g = 0; g < MDX_MAX_TC; g++) {
+        rs[MDX_RS_LAMBDA + g] = h->lambda[g]; rs[MDX_RS_THERM_INTEGRAL + g] = h->therm_integral[g];
+        rs[MDX_RS_EKINH + g] = h->ekinh[g]; rs[MDX_RS_EKINH_OLD + g] = h->ekinh_old[g];
+    }
+    for (int a = 0; a < 9; a++) { rs[MDX_RS_PR_BOXV + a] = h->pr_boxv[a]; rs[MDX_RS_MU + a] = h->mu[a]; }
+    rs[MDX_RS_BARO_INTEGRAL] = h->baro_integral;
+    rs[MDX_RS_PULL_INIT] = h->pull_init; rs[MDX_RS_PULL_WORK] = h->pull_work; rs[MDX_RS_PULL_VALUE] = h->pull_value;
+    rs[MDX_RS_PULL_HAVE_INIT] = h->pull_have_init ? 1.0 : 0.0;
+    for (int a = 0; a < 4; a++) rs[MDX_RS_COM_V + a] = h->com_v[a];
+    return MDX_OK;
+}
+
+extern "C" int mdx_set_run_state(mdx_system *s, const double *rs)
+{
+    (void)hipSetDevice(s->device);
+    ARG_CHECK(s, rs, "mdx_set_run_state: null pointer");
+    int rc = sync_and_check(s); if (rc) return rc;
+    DevState *h = s->h;
+    for (int g = 0; g < MDX_MAX_TC; g++) { h->lambda[g] = rs[MDX_RS_LAMBDA + g]; h->therm_integral[g] = rs[MDX_RS_THERM_INTEGRAL + g]; }
+    for (int a = 0; a < 9; a++) h->pr_boxv[a] = rs[MDX_RS_PR_BOXV + a];
+    // the velocity coupling matrix follows from the box velocity (isotropic: every element shares one relative rate)
+    const double rate = h->boxd[0] > 0.0 ? h->pr_boxv[0] / h->boxd[0] : 0.0;
+    for (int a = 0; a < 9; a++) h->pr_M[a] = (a % 4 == 0 && s->pcoupl == 2) ? 2.0 * rate : 0.0;
+    h->baro_integral = rs[MDX_RS_BARO_INTEGRAL];
+    h->pull_init = rs[MDX_RS_PULL_INIT]; h->pull_work = rs[MDX_RS_PULL_WORK]; h->pull_value = rs[MDX_RS_PULL_VALUE];
+    h->pull_have_init = rs[MDX_RS_PULL_HAVE_INIT] != 0.0 ? 1 : 0;
+#define RS_UP(field) MDX_CHECK(s, hipMemcpyAsync((char *)s->d + offsetof(DevState, field), (char *)h + offsetof(DevState, field), sizeof(h->field), hipMemcpyHostToDevice, s->stream))
+    RS_UP(lambda); RS_UP(therm_integral); RS_UP(pr_boxv); RS_UP(pr_M); RS_UP(baro_integral);
+    RS_UP(pull_init); RS_UP(pull_work); RS_UP(pull_value); RS_UP(pull_have_init);
+#undef RS_UP
+    MDX_CHECK(s, hipStreamSynchronize(s->stream));
+    // the restored scaling factors are the ones the interrupted run would have used next: do not redraw them, and
+    // keep the restored pull reference instead of re-seeding it from the restart geometry
+    s->first_step = false;
+    if (h->pull_have_init) s->pull_reset_pending = false;
+    return MDX_OK;
+}
+
 // ---------------------------------------------------------------- compute
 static int record_energy_frame(mdx_system *s)
 {
@@ -675,6 +721,9 @@ extern "C" int mdx_get_list_stats(mdx_system *s, long long *st)
     return MDX_OK;
 }
 
+// Kernel timing uses a pool of events created when timing is switched on (creating an event costs tens of
+// microseconds of host time, which has no place in the launch path); drain_timing reads the pairs used so far and
+// makes the pool available again.
 static int drain_timing(mdx_system *s)
 {
     if (s->ev_nb.empty()) return MDX_OK;
@@ -683,8 +732,7 @@ static int drain_timing(mdx_system *s)
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, s->ev_pool[p.first], s->ev_pool[p.second]) == hipSuccess) { s->nb_ms_total += ms; s->nb_launches++; }
     }
-    for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
-    s->ev_pool.clear(); s->ev_nb.clear();
+    s->ev_nb.clear();
     return MDX_OK;
 }
 
@@ -693,6 +741,15 @@ extern "C" int mdx_enable_kernel_timing(mdx_system *s, int on)
     (void)hipSetDevice(s->device);
     int rc = drain_timing(s); if (rc) return rc;
     s->time_nb = on != 0; s->nb_ms_total = 0; s->nb_launches = 0;
+    s->time_stride = on > 1 ? on : 1;
+    if (on && s->ev_pool.empty()) {
+        s->ev_pool.resize(2 * 1024);
+        for (hipEvent_t &e : s->ev_pool) MDX_CHECK(s, hipEventCreate(&e));
+    }
+    if (!on) {
+        for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
+        s->ev_pool.clear();
+    }
     return MDX_OK;
 }
 
@@ -802,7 +859,6 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early)
     s->step++;
     s->steps_since_search++;
     s->forces_current = false;
-    if (s->time_nb && s->ev_pool.size() > 8192) if ((rc = drain_timing(s))) return rc;
     return MDX_OK;
 }
 

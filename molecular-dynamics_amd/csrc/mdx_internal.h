@@ -228,7 +228,7 @@ struct mdx_system {
     // timing of the dominant kernel (HIP events on this stream)
     unsigned nb_launch_seq = 0;
     bool pme_signalled = false;        // ev_pme already attached to the last kernel of the PME chain
-    bool time_nb = false; std::vector<hipEvent_t> ev_pool; std::vector<std::pair<int, int>> ev_nb;
+    bool time_nb = false; int time_stride = 7; std::vector<hipEvent_t> ev_pool; std::vector<std::pair<int, int>> ev_nb;
     double nb_ms_total = 0; long long nb_launches = 0;
     // domain decomposition (csrc/domdec.hip)
     bool dd_on = false;

@@ -462,11 +462,22 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
     // packet, so they read the kernel's begin and end time stamps (no marker packets, no launch gap inside)
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     // (force-only launches only, at a stride that does not lock onto the 10- and 20-step cadences of energy and search steps)
-    const bool timed = s->time_nb && (s->nb_launch_seq++ % 7 == 0) && !energy;
+    const bool timed = s->time_nb && (s->nb_launch_seq++ % (unsigned)s->time_stride == 0) && !energy;
     if (timed) {
-        if (hipEventCreate(&ev_a) != hipSuccess || hipEventCreate(&ev_b) != hipSuccess) { s->err = "hipEventCreate failed"; return MDX_ERR_HIP; }
-        s->ev_pool.push_back(ev_a); s->ev_pool.push_back(ev_b);
-        s->ev_nb.push_back(std::make_pair((int)s->ev_pool.size() - 2, (int)s->ev_pool.size() - 1));
+        // the pool is full: read the pairs recorded so far (waits for the stream) and start over
+        if (2 * (s->ev_nb.size() + 1) > s->ev_pool.size()) {
+            if (hipStreamSynchronize(s->stream) != hipSuccess) { s->err = "hipStreamSynchronize failed"; return MDX_ERR_HIP; }
+            for (auto &p : s->ev_nb) {
+                float ms = 0.0f;
+                if (hipEventElapsedTime(&ms, s->ev_pool[p.first], s->ev_pool[p.second]) == hipSuccess) { s->nb_ms_total += ms; s->nb_launches++; }
+            }
+            s->ev_nb.clear();
+        }
+        const int k = 2 * (int)s->ev_nb.size();
+        if (k + 1 < (int)s->ev_pool.size()) {
+            ev_a = s->ev_pool[k]; ev_b = s->ev_pool[k + 1];
+            s->ev_nb.push_back(std::make_pair(k, k + 1));
+        }
     }
     void (*kern)(NbArgs) = k_nonbonded_f;
     dim3 grid(nblk), block(256);

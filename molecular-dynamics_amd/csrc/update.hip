@@ -6,13 +6,15 @@
 #include "mdx_internal.h"
 #include <algorithm>
 
-// v' = lambda_g * (v + f/m dt) - dt * M v  (M: Parrinello-Rahman coupling matrix, zero otherwise);
-// xp = x + v' dt. Total force = original-order array + sorted nonbonded buffer.
+// v' = lambda_g v + f/m dt - dt_pc M v  (lambda_g: V-rescale factor of the atom's group, drawn from the kinetic
+// energy of v itself, so it scales v and not the force kick; M: Parrinello-Rahman coupling matrix, held between
+// coupling steps and applied every step over dt_pc = dt); xp = x + v' dt.
+// Total force = original-order array + sorted nonbonded buffer.
 __global__ __launch_bounds__(256) void k_leapfrog(int n, const float4 *__restrict__ x, float4 *__restrict__ xp,
                                                   float4 *__restrict__ v, float *__restrict__ f, const float *__restrict__ f_pme,
                                                   const float *__restrict__ f_s, const int *__restrict__ sorted_of,
                                                   const int *__restrict__ tcgrp, const DevState *__restrict__ d, float dt,
-                                                  int use_lambda, int use_pr)
+                                                  int use_lambda, int use_pr, float dt_pc)
 {
     MDX_STAMP(d, 11);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -28,13 +30,12 @@ __global__ __launch_bounds__(256) void k_leapfrog(int n, const float4 *__restric
     const float im = vi.w;
     float lam = 1.0f;
     if (use_lambda) lam = (float)d->lambda[tcgrp[i]];
-    float nx = vi.x + fx * im * dt, ny = vi.y + fy * im * dt, nz = vi.z + fz * im * dt;
-    nx *= lam; ny *= lam; nz *= lam;
+    float nx = fmaf(lam, vi.x, fx * im * dt), ny = fmaf(lam, vi.y, fy * im * dt), nz = fmaf(lam, vi.z, fz * im * dt);
     if (use_pr) {
         const double *M = d->pr_M;
-        nx -= dt * (float)(M[0] * vi.x + M[1] * vi.y + M[2] * vi.z);
-        ny -= dt * (float)(M[3] * vi.x + M[4] * vi.y + M[5] * vi.z);
-        nz -= dt * (float)(M[6] * vi.x + M[7] * vi.y + M[8] * vi.z);
+        nx -= dt_pc * (float)(M[0] * vi.x + M[1] * vi.y + M[2] * vi.z);
+        ny -= dt_pc * (float)(M[3] * vi.x + M[4] * vi.y + M[5] * vi.z);
+        nz -= dt_pc * (float)(M[6] * vi.x + M[7] * vi.y + M[8] * vi.z);
     }
     vi.x = nx; vi.y = ny; vi.z = nz;
     v[i] = vi;
@@ -392,23 +393,32 @@ __global__ void k_pcouple(DevState *dw, int kind, double tau_p, double ref_p, do
         // work done by the scaling: -P0 dV (+ kinetic part through v scaling is handled by ekin)
         dw->baro_integral -= 0.0;
     } else if (kind == 2) {
-        // isotropic: every box element follows the same relative rate
-        double maxl = fmax(b[0], fmax(b[4], b[8]));
+        // Isotropic Parrinello-Rahman as GROMACS defines it [GMX-doc, "Parrinello-Rahman pressure coupling"]:
+        // W^-1 = 4 pi^2 beta / (3 tau_p^2 L_max); the "force" on the box is t = b^-1T (P - P_ref) (the box rows are the
+        // cell vectors, so the off-diagonal pressure elements enter through the off-diagonal elements of b^-1 in a
+        // triclinic cell); the isotropic variant turns its diagonal into one relative acceleration
+        // a_rel = (1/3) sum_d t_dd / b_dd shared by every box element: d(b')/dt += dt_pc V W^-1 a_rel b.
+        const double maxl = fmax(b[0], fmax(b[4], b[8]));
         const double winv = 4.0 * M_PI * M_PI * compress / (3.0 * tau_p * tau_p * maxl);
-        // d2b/dt2 = V W^-1 b'^-1 (P - Pref): for isotropic scaling b'^-1 (P-Pref) -> (P - Pref)/b_ii
-        for (int a = 0; a < 9; a++) {
-            const int r = a / 3, c = a % 3;
-            double acc = 0.0;
-            if (r == c) acc = vol * winv * (P - ref_p) / b[a];
-            dw->pr_boxv[a] += dt_pc * acc;
+        const double ia = 1.0 / b[0], ie = 1.0 / b[4], ii = 1.0 / b[8];
+        const double binv[9] = { ia, 0, 0, -b[3] * ia * ie, ie, 0, (b[3] * b[7] - b[4] * b[6]) * ia * ie * ii, -b[7] * ie * ii, ii };
+        double arel = 0.0;
+        for (int dd = 0; dd < 3; dd++) {
+            double t = 0.0;
+            for (int k = 0; k < 3; k++) t += binv[3 * k + dd] * (dw->pres[3 * k + dd] - (k == dd ? ref_p : 0.0));
+            arel += t / b[4 * dd];
         }
-        // isotropic: average the diagonal relative rates and apply to all elements
-        const double rate = (dw->pr_boxv[0] / b[0] + dw->pr_boxv[4] / b[4] + dw->pr_boxv[8] / b[8]) / 3.0;
-        for (int a = 0; a < 9; a++) dw->pr_boxv[a] = rate * b[a];
+        arel /= 3.0;
+        for (int a = 0; a < 9; a++) dw->pr_boxv[a] += dt_pc * vol * winv * arel * b[a];
+        // every element moves at the same relative rate: mu = 1 + rate dt_pc, M = b^-1 (b db'/dt + db/dt b') b'^-1 = 2 rate
+        const double rate = dw->pr_boxv[0] / b[0];
         const double m = 1.0 + rate * dt_pc;
         mu[0] = mu[4] = mu[8] = m;
-        // velocity coupling M = b^-1 (b db'/dt + db/dt b') b'^-1 = 2 rate I for isotropic scaling
         dw->pr_M[0] = dw->pr_M[4] = dw->pr_M[8] = 2.0 * rate;
+        // conserved-energy part of the barostat: P_ref V + kinetic energy of the box, 1/2 sum (db_ij/dt)^2 / W^-1
+        double kbox = 0.0;
+        for (int a = 0; a < 9; a++) kbox += 0.5 * dw->pr_boxv[a] * dw->pr_boxv[a] / (winv * MDX_PRESFAC);
+        dw->baro_integral = kbox + ref_p * vol * m * m * m / MDX_PRESFAC;
     }
     for (int a = 0; a < 9; a++) dw->mu[a] = mu[a];
     for (int a = 0; a < 3; a++) { dw->posres_com_old[a] = dw->posres_com[a]; dw->posres_com[a] *= mu[0]; }
@@ -488,7 +498,7 @@ int mdx_launch_update(mdx_system *s, bool do_tc, bool do_pr, bool virial)
 {
     const int nb = (s->n + 255) / 256;
     hipLaunchKernelGGL(k_leapfrog, dim3(nb), dim3(256), 0, s->stream, s->n, s->x, s->xp, s->v, s->f, s->f_pme, s->f_s, s->sorted_of,
-                       s->tcgrp, s->d, s->dt, do_tc ? 1 : 0, do_pr ? 1 : 0);
+                       s->tcgrp, s->d, s->dt, do_tc ? 1 : 0, do_pr ? 1 : 0, s->dt);
     int rc = mdx_launch_constrain(s, 1.0f / s->dt, virial, s->lincs_iter);
     if (rc) return rc;
     // the constrained new positions become the state

@@ -17,6 +17,10 @@ E_NAMES = ["LJ", "COUL_SR", "COUL_RECIP", "COUL_EXCL", "BOND", "ANGLE", "DIH", "
 E_N = len(E_NAMES)
 E = {n: i for i, n in enumerate(E_NAMES)}
 F_NONBONDED, F_PME, F_EXCL, F_BONDED, F_POSRES, F_PULL, F_ALL = 1, 2, 4, 8, 16, 32, 63
+# layout of the run state (MDX_RS_* in include/mdx.h)
+RS = dict(LAMBDA=0, THERM_INTEGRAL=8, EKINH=16, EKINH_OLD=24, PR_BOXV=32, MU=41, BARO_INTEGRAL=50, PULL_INIT=51, PULL_WORK=52,
+          PULL_VALUE=53, PULL_HAVE_INIT=54, COM_V=55)
+RS_N = 64
 
 _LIB = None
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmdx.so")
@@ -26,7 +30,7 @@ SYMBOLS = [
     "mdx_set_bonds", "mdx_set_angles", "mdx_set_dihedrals", "mdx_set_pairs14", "mdx_set_posres", "mdx_get_posres_ref", "mdx_set_settles",
     "mdx_set_constraints", "mdx_set_nonbonded", "mdx_set_pme", "mdx_set_integrator", "mdx_set_tcoupl",
     "mdx_set_pcoupl", "mdx_set_dispcorr", "mdx_set_pull", "mdx_set_state", "mdx_set_state_device", "mdx_get_state",
-    "mdx_get_step", "mdx_compute_forces", "mdx_get_forces", "mdx_get_energies", "mdx_get_virial", "mdx_step",
+    "mdx_get_step", "mdx_get_run_state", "mdx_set_run_state", "mdx_compute_forces", "mdx_get_forces", "mdx_get_energies", "mdx_get_virial", "mdx_step",
     "mdx_synchronize", "mdx_get_list_stats", "mdx_pop_energy_frames", "mdx_pop_pull_records",
     "mdx_enable_kernel_timing", "mdx_get_kernel_timing", "mdx_debug_time_nonbonded", "mdx_debug_set", "mdx_debug_wave_times", "mdx_debug_stamps",
     "mdx_dd_load", "mdx_dd_pack", "mdx_dd_unpack", "mdx_dd_step_begin", "mdx_dd_wait_spread", "mdx_dd_step_end", "mdx_dd_grid",
@@ -79,6 +83,8 @@ def load_library(path: str | None = None):
     L.mdx_set_state_device.argtypes = [vp, vp, vp, fp]
     L.mdx_get_state.argtypes = [vp, fp, fp, fp]
     L.mdx_get_step.restype = ctypes.c_longlong; L.mdx_get_step.argtypes = [vp]
+    L.mdx_get_run_state.argtypes = [vp, dp]
+    L.mdx_set_run_state.argtypes = [vp, dp]
     L.mdx_compute_forces.argtypes = [vp, ctypes.c_uint]
     L.mdx_get_forces.argtypes = [vp, fp]
     L.mdx_get_energies.argtypes = [vp, dp]
@@ -299,6 +305,7 @@ class Engine:
                 # the 3 COM degrees of freedom are removed proportionally
                 ndf.append(nd - 3.0 * nd / total_ndf if nstcomm > 0 else nd)
         self.ntc = len(tc_groups) if tc_groups else 0
+        self.ndf = [float(d) for d in ndf]          # degrees of freedom per T-coupling group, as handed to the library
         self.ndf_total = float(3.0 * n - nc_atom.sum() - (3.0 if nstcomm > 0 else 0.0))
         self._call("mdx_set_nonbonded", ctypes.c_float(self.rc), ctypes.c_float(self.rlist), ctypes.c_float(self.beta if pme else 0.0),
                    int(nstlist))
@@ -422,6 +429,18 @@ class Engine:
     def set_step(self, step):
         self._call("mdx_set_step", ctypes.c_longlong(int(step)))
 
+    def get_run_state(self):
+        """The MDX_RS_N coupling / pull scalars a checkpoint carries beside x, v and box (layout in include/mdx.h)."""
+        rs = np.zeros(RS_N, np.float64)
+        self._call("mdx_get_run_state", _p(rs, ctypes.c_double))
+        return rs
+
+    def set_run_state(self, rs):
+        rs = np.ascontiguousarray(rs, dtype=np.float64)
+        if rs.shape != (RS_N,):
+            raise MdxError(f"run state must hold {RS_N} values")
+        self._call("mdx_set_run_state", _p(rs, ctypes.c_double))
+
     def generate_velocities(self, temperature, seed):
         self._call("mdx_generate_velocities", float(temperature), ctypes.c_ulonglong(int(seed) & (2 ** 64 - 1)))
 
@@ -477,8 +496,8 @@ class Engine:
             raise MdxError("mdx_pop_pull_records failed: " + self.lib.mdx_last_error(self.h).decode())
         return buf[:n]
 
-    def enable_kernel_timing(self, on=True):
-        self._call("mdx_enable_kernel_timing", 1 if on else 0)
+    def enable_kernel_timing(self, on=True, stride=7):
+        self._call("mdx_enable_kernel_timing", int(stride) if on else 0)
 
     def debug_time_nonbonded(self, energy=False, iters=50):
         ms = ctypes.c_double(0)

@@ -69,6 +69,12 @@ class FramePipeline:
                 self._next_commit += 1
                 self._cv.notify_all()
 
+    def wait_idle(self):
+        """Blocks until every frame submitted so far has been encoded and committed; the threads stay up."""
+        with self._cv:
+            while self._next_commit != self._seq:
+                self._cv.wait()
+
     def finish(self):
         for _ in self.threads:
             self.q.put(None)

@@ -391,6 +391,7 @@ def mdrun(argv, out=sys.stdout, err=sys.stderr) -> int:
 
     # ---- continuation from a checkpoint
     step0 = 0
+    run_state0 = None
     appending = False
     cpi = a.cpi
     if cpi == "":
@@ -409,6 +410,7 @@ def mdrun(argv, out=sys.stdout, err=sys.stderr) -> int:
             sysm.posres_ref = ref @ carry if mode == "all" else ref + (ref.mean(0) @ carry - ref.mean(0))
         sysm.x, sysm.v, sysm.box = cp["x"], cp["v"], cp["box"]
         step0 = int(cp["step"])
+        run_state0 = cp.get("extra", {}).get("run_state")
         appending = a.append
     elif cpi is not None:
         out.write(f"NOTE: checkpoint {cpi} not found, starting from the run input\n")
@@ -480,7 +482,7 @@ def mdrun(argv, out=sys.stdout, err=sys.stderr) -> int:
         x, v, box = eng.get_state()
         groio.write_system_gro(f_gro, sysm, x=x, v=v, box=box, title=f"{sysm.title}, t= {tinit + step_now * dt:.5f} step= {step_now}")
         if with_cpt:
-            tprio.save_checkpoint(f_cpt, step_now, tinit + step_now * dt, x, v, box)
+            tprio.save_checkpoint(f_cpt, step_now, tinit + step_now * dt, x, v, box, extra=dict(run_state=[float(r) for r in eng.get_run_state()]))
 
     rc = 0
     try:
@@ -528,6 +530,10 @@ def mdrun(argv, out=sys.stdout, err=sys.stderr) -> int:
                 _backup(f_px); _backup(f_pf)
             px = xvgio.pullx_writer(f_px, append=appending) if nst_px > 0 else None
             pf = xvgio.pullf_writer(f_pf, append=appending) if nst_pf > 0 else None
+        if step0 and run_state0 is not None:
+            # thermostat factors, barostat box velocity, pull reference and work of the interrupted run
+            eng.set_run_state(np.asarray(run_state0, dtype=np.float64))
+            log.note("Restored the coupling and pull state from the checkpoint")
         # ---- trajectory output
         nst_xtc, nst_x, nst_v = m.i("nstxout_compressed"), m.i("nstxout"), m.i("nstvout")
         if m.i("nstfout"):
@@ -624,7 +630,7 @@ def mdrun(argv, out=sys.stdout, err=sys.stderr) -> int:
                 last_print = now
                 if a.cpt > 0 and now - last_cpt >= a.cpt * 60.0:
                     x_, v_, b_ = eng.get_state()
-                    tprio.save_checkpoint(f_cpt, step, tinit + step * dt, x_, v_, b_)
+                    tprio.save_checkpoint(f_cpt, step, tinit + step * dt, x_, v_, b_, extra=dict(run_state=[float(r) for r in eng.get_run_state()]))
                     last_cpt = now
         # the frame of the final step
         if not stop["flag"]:

@@ -451,17 +451,156 @@ def pull_distance(x, box, mass, g1, g2, pbc1=None, pbc2=None):
     return r, dr / r, coms[0], coms[1]
 
 
-def md_step(s, v, rc, beta, grid, dt, nthreads=4):
-    """One plain leap-frog step with all force terms, SETTLE and LINCS (no coupling): the
-    per-step work of `gmx mdrun` for `integrator = md`, restated for the CPU baseline timing."""
+def md_step(s, v, rc, beta, grid, dt, nthreads=4, lam=None, extra_force=None):
+    """One leap-frog step with all force terms, SETTLE and LINCS: the per-step work of `gmx mdrun` for
+    `integrator = md`. `lam` (per atom, or None) is the V-rescale factor of the atom's T-coupling group: it scales
+    the old half-step velocity, v' = lam v + f/m dt (Bussi 2007 applied to leap-frog). The constraint displacement
+    is returned in out["dx_constr"] (constraint force = m dx / dt^2)."""
     out = all_forces(s, rc, beta, grid, nthreads)
+    if extra_force is not None:
+        out["f"] = out["f"] + extra_force
     invm = 1.0 / s.mass
-    v_new = v + out["f"] * invm[:, None] * dt
+    v_old = v if lam is None else np.asarray(lam, dtype=np.float64)[:, None] * v
+    v_new = v_old + out["f"] * invm[:, None] * dt
     x_new = s.x + v_new * dt
     xc = x_new
     if len(s.settles):
         xc = settle_water(s.x, xc, s.settles, s.mass[s.settles[0, 0]], s.mass[s.settles[0, 1]], s.settle_doh, s.settle_dhh)
     if len(s.constraints):
         xc = lincs(s.x, xc, s.constraints, s.constraint_len, invm, 4, 1)
+    out["dx_constr"] = xc - x_new
     v_new = v_new + (xc - x_new) / dt
     return xc, v_new, out
+
+
+# ------------------------------------------------------------------ counter-based random numbers
+_M32 = 0xFFFFFFFF
+
+
+def philox4x32(ctr_lo, ctr_hi, key):
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11): 128-bit counter (ctr_lo, ctr_hi as two 64-bit words),
+    64-bit key; returns the four 32-bit outputs. Arguments may be Python ints or numpy uint64 arrays."""
+    lo = np.asarray(ctr_lo, dtype=np.uint64); hi = np.asarray(ctr_hi, dtype=np.uint64); k = np.asarray(key, dtype=np.uint64)
+    m32 = np.uint64(_M32); s32 = np.uint64(32)
+    c0, c1, c2, c3 = lo & m32, lo >> s32, hi & m32, hi >> s32
+    k0, k1 = k & m32, k >> s32
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c0
+        p1 = np.uint64(0xCD9E8D57) * c2
+        c0, c1, c2, c3 = (p1 >> s32) ^ c1 ^ k0, p1 & m32, (p0 >> s32) ^ c3 ^ k1, p0 & m32
+        k0 = (k0 + np.uint64(0x9E3779B9)) & m32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & m32
+    return c0, c1, c2, c3
+
+
+def _u53(a, b):
+    """Uniform double in (0, 1) from two 32-bit words: the top 53 bits of (a << 32 | b), centred."""
+    m = ((np.asarray(a, dtype=np.uint64) << np.uint64(32)) | np.asarray(b, dtype=np.uint64)) >> np.uint64(11)
+    return (m.astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
+
+
+class RngStream:
+    """The engine's stream convention on top of Philox: key = seed, high counter word = stream id, low counter
+    word = (step << 16) + block; every block yields two uniforms (words 0-1, then 2-3). Gaussians by Box-Muller
+    (cosine branch), Gamma(a >= 1) by Marsaglia & Tsang (2000), chi^2(n) = 2 Gamma(n/2)."""
+
+    def __init__(self, key, stream_id, step):
+        self.key, self.hi, self.lo = int(key), int(stream_id), int(step) << 16
+        self.buf, self.have = None, 0
+
+    def uniform(self):
+        if self.have < 2:
+            self.buf = [int(w) for w in philox4x32(self.lo, self.hi, self.key)]
+            self.lo += 1; self.have = 4
+        a, b = self.buf[4 - self.have], self.buf[5 - self.have]
+        self.have -= 2
+        return float(_u53(a, b))
+
+    def gauss(self):
+        u1 = self.uniform(); u2 = self.uniform()
+        return float(np.sqrt(-2.0 * np.log(u1)) * np.cos(6.283185307179586 * u2))
+
+    def gamma(self, a):
+        d = a - 1.0 / 3.0; c = 1.0 / np.sqrt(9.0 * d)
+        for _ in range(64):
+            while True:
+                xg = self.gauss(); v = 1.0 + c * xg
+                if v > 0.0:
+                    break
+            v = v * v * v
+            u = self.uniform()
+            if u < 1.0 - 0.0331 * xg ** 4:
+                return d * v
+            if np.log(u) < 0.5 * xg * xg + d * (1.0 - v + np.log(v)):
+                return d * v
+        return d
+
+    def chi2(self, n):
+        if n <= 0.0:
+            return 0.0
+        if n < 2.0:
+            return sum(self.gauss() ** 2 for _ in range(int(n)))
+        return 2.0 * self.gamma(0.5 * n)
+
+
+STREAM_TCOUPLE = 0x7c0000      # + T-group index
+STREAM_PCOUPLE = 0xba0000
+STREAM_GENVEL = 0x9e0000
+
+
+def vrescale_lambda(ek, ref_t, tau_t, ndf, dt_tc, seed, group, step):
+    """V-rescale scaling factor of one T-coupling group for the draws of (seed, group, step): Gaussian first,
+    then chi^2(ndf - 1). Returns (lambda, new kinetic energy)."""
+    rng = RngStream(seed, STREAM_TCOUPLE + group, step)
+    r1 = rng.gauss()
+    rs = rng.chi2(ndf - 1.0)
+    eknew = vrescale_new_ekin(ek, 0.5 * ndf * BOLTZ * ref_t, ndf, dt_tc, tau_t, r1, rs)
+    return float(np.sqrt(max(eknew, 0.0) / ek)), float(eknew)
+
+
+def crescale_gauss(seed, step):
+    return RngStream(seed, STREAM_PCOUPLE, step).gauss()
+
+
+def generate_velocities(mass, temperature, seed):
+    """`gen_vel = yes` (/root/reference/mdp/nvt_complex.mdp:39-41): Maxwell-Boltzmann components
+    sqrt(kT/m) N(0,1) from one Philox stream per atom (three Box-Muller Gaussians = three blocks), centre-of-mass
+    velocity removed, then scaled to exactly `temperature` over 3N degrees of freedom. Massless atoms get zero."""
+    m = np.asarray(mass, dtype=np.float64)
+    n = len(m)
+    i = np.arange(n, dtype=np.uint64)
+    g = np.zeros((n, 3))
+    for b in range(3):
+        w = philox4x32((i << np.uint64(16)) + np.uint64(b), np.uint64(STREAM_GENVEL), np.uint64(int(seed) & 0xFFFFFFFFFFFFFFFF))
+        g[:, b] = np.sqrt(-2.0 * np.log(_u53(w[0], w[1]))) * np.cos(6.283185307179586 * _u53(w[2], w[3]))
+    # the engine keeps inverse masses in float32
+    im = np.where(m > 0, (1.0 / m.astype(np.float32)).astype(np.float64), 0.0)
+    v = (np.sqrt(BOLTZ * temperature * im)[:, None] * g).astype(np.float32).astype(np.float64)
+    mm = np.where(im > 0, 1.0 / np.where(im > 0, im, 1.0), 0.0)
+    v = (v - ((mm[:, None] * v).sum(0) / mm.sum())[None, :]).astype(np.float32).astype(np.float64)
+    ek = 0.5 * (mm[:, None] * v * v).sum()
+    return v * np.sqrt(0.5 * 3.0 * n * BOLTZ * temperature / ek)
+
+
+def remove_com_velocity(v, mass):
+    """Linear centre-of-mass motion removal (`comm-mode = Linear`, /root/reference/mdp/npt_complex.mdp:64-66)."""
+    m = np.asarray(mass, dtype=np.float64)
+    return v - ((m[:, None] * v).sum(0) / m.sum())[None, :]
+
+
+def parrinello_rahman_step(box, boxv, pres, ref_p, compress, tau_p, dt_pc):
+    """One coupling step of the isotropic Parrinello-Rahman barostat (Parrinello & Rahman 1981 in the form of the
+    GROMACS manual, `pcoupl = Parrinello-Rahman`, `pcoupltype = isotropic`, /root/reference/mdp/production.mdp:36-40):
+    W^-1 = 4 pi^2 beta / (3 tau_p^2 L_max); t = b^-T (P - P_ref); a_rel = (1/3) sum_d t_dd / b_dd;
+    db'/dt += dt_pc V W^-1 a_rel b; mu = 1 + (b'_xx / b_xx) dt_pc; M = 2 (b'_xx / b_xx) 1.
+    box rows are the cell vectors (nm), pres in bar. Returns (new box, new boxv, mu, M)."""
+    b = np.asarray(box, dtype=np.float64); bv = np.asarray(boxv, dtype=np.float64).copy()
+    P = np.asarray(pres, dtype=np.float64).reshape(3, 3)
+    vol = abs(np.linalg.det(b))
+    winv = 4.0 * np.pi ** 2 * compress / (3.0 * tau_p ** 2 * max(b[0, 0], b[1, 1], b[2, 2]))
+    t = np.linalg.inv(b).T @ (P - ref_p * np.eye(3))
+    arel = sum(t[d, d] / b[d, d] for d in range(3)) / 3.0
+    bv += dt_pc * vol * winv * arel * b
+    rate = bv[0, 0] / b[0, 0]
+    mu = 1.0 + rate * dt_pc
+    return b * mu, bv, mu, 2.0 * rate * np.eye(3)
