@@ -30,6 +30,27 @@ static int dev_upload(mdx_system *s, T **p, const std::vector<T> &h)
     return MDX_OK;
 }
 
+// ---------------------------------------------------------------- scratch for the entry point that allocates nothing
+// mdx_get_forces_noalloc stages the merged forces here instead of in a buffer it allocates per call. The array is
+// part of the code object: every GPU the library runs on holds its own copy, at its own address, until the process
+// ends. Host code never uses the array's name as an address; the address on a device is taken once, with that device
+// current (mdx_create), and kept in g_scratch_ptr.
+#define MDX_NOALLOC_MAX_ATOMS (1 << 20)
+#define MDX_MAX_DEVICES 64
+static __device__ __align__(256) float scratch[3 * (size_t)MDX_NOALLOC_MAX_ATOMS];      // 12 MiB
+static float *g_scratch_ptr[MDX_MAX_DEVICES] = { nullptr };
+static hipError_t g_scratch_err[MDX_MAX_DEVICES] = { hipSuccess };
+
+// With `device` current: look the device's copy of `scratch` up once.
+static void scratch_lookup(int device)
+{
+    if (device < 0 || device >= MDX_MAX_DEVICES || g_scratch_ptr[device]) return;
+    float *p = nullptr;
+    const hipError_t e = hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch));
+    g_scratch_err[device] = e;
+    g_scratch_ptr[device] = (e == hipSuccess) ? p : nullptr;
+}
+
 extern "C" int mdx_version(void) { return 100; }
 
 extern "C" const char *mdx_last_error(const mdx_system *sys)
@@ -57,6 +78,7 @@ extern "C" mdx_system *mdx_create(int device, int natoms)
     }
     if (device < 0 || device >= ndev) { g_create_err = "device index out of range"; return nullptr; }
     if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return nullptr; }
+    scratch_lookup(device);
     mdx_system *s = new mdx_system();
     s->device = device; s->n = natoms;
     // the side streams get the highest priority so that their small kernels take wave slots as soon
@@ -689,6 +711,33 @@ extern "C" int mdx_get_forces(mdx_system *s, float *f)
     MDX_CHECK(s, hipMemcpyAsync(f, tmp, sizeof(float) * 3 * s->n, hipMemcpyDeviceToHost, s->stream));
     MDX_CHECK(s, hipStreamSynchronize(s->stream));
     (void)hipFree(tmp);
+    return MDX_OK;
+}
+
+// mdx_get_forces without any allocation: the merged forces are staged in the file-scope scratch array of the
+// handle's device (address looked up at mdx_create), then copied to the caller's buffer on the handle's stream.
+// All handles on one GPU share that array: calls that overlap on one GPU race.
+extern "C" int mdx_get_forces_noalloc(mdx_system *s, float *f)
+{
+    (void)hipSetDevice(s->device);
+    ARG_CHECK(s, f, "mdx_get_forces_noalloc: null pointer");
+    if (s->n > MDX_NOALLOC_MAX_ATOMS) {
+        s->err = "mdx_get_forces_noalloc: " + std::to_string(s->n) + " atoms exceed the fixed scratch of " +
+                 std::to_string(MDX_NOALLOC_MAX_ATOMS) + " atoms (use mdx_get_forces)";
+        return MDX_ERR_OVERFLOW;
+    }
+    ARG_CHECK(s, s->forces_current, "mdx_get_forces_noalloc: no forces computed at the current positions");
+    float *stage = (s->device >= 0 && s->device < MDX_MAX_DEVICES) ? g_scratch_ptr[s->device] : nullptr;
+    if (!stage) {
+        s->err = std::string("mdx_get_forces_noalloc: no scratch on this device (hipGetSymbolAddress: ") +
+                 hipGetErrorString(s->device >= 0 && s->device < MDX_MAX_DEVICES ? g_scratch_err[s->device] : hipErrorInvalidDevice) + ")";
+        return MDX_ERR_HIP;
+    }
+    // every one of the 3n staged values is written by the merge kernel: nothing of an earlier call survives
+    int rc = mdx_launch_merge_forces(s, stage);
+    if (rc) return rc;
+    MDX_CHECK(s, hipMemcpyAsync(f, stage, sizeof(float) * 3 * s->n, hipMemcpyDeviceToHost, s->stream));
+    MDX_CHECK(s, hipStreamSynchronize(s->stream));
     return MDX_OK;
 }
 

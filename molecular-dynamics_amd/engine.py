@@ -30,7 +30,7 @@ SYMBOLS = [
     "mdx_set_bonds", "mdx_set_angles", "mdx_set_dihedrals", "mdx_set_pairs14", "mdx_set_posres", "mdx_get_posres_ref", "mdx_set_settles",
     "mdx_set_constraints", "mdx_set_nonbonded", "mdx_set_pme", "mdx_set_integrator", "mdx_set_tcoupl",
     "mdx_set_pcoupl", "mdx_set_dispcorr", "mdx_set_pull", "mdx_set_state", "mdx_set_state_device", "mdx_get_state",
-    "mdx_get_step", "mdx_get_run_state", "mdx_set_run_state", "mdx_compute_forces", "mdx_get_forces", "mdx_get_energies", "mdx_get_virial", "mdx_step",
+    "mdx_get_step", "mdx_get_run_state", "mdx_set_run_state", "mdx_compute_forces", "mdx_get_forces", "mdx_get_forces_noalloc", "mdx_get_energies", "mdx_get_virial", "mdx_step",
     "mdx_synchronize", "mdx_get_list_stats", "mdx_pop_energy_frames", "mdx_pop_pull_records",
     "mdx_enable_kernel_timing", "mdx_get_kernel_timing", "mdx_debug_time_nonbonded", "mdx_debug_set", "mdx_debug_wave_times", "mdx_debug_stamps",
     "mdx_dd_load", "mdx_dd_pack", "mdx_dd_unpack", "mdx_dd_step_begin", "mdx_dd_wait_spread", "mdx_dd_step_end", "mdx_dd_grid",
@@ -87,6 +87,7 @@ def load_library(path: str | None = None):
     L.mdx_set_run_state.argtypes = [vp, dp]
     L.mdx_compute_forces.argtypes = [vp, ctypes.c_uint]
     L.mdx_get_forces.argtypes = [vp, fp]
+    L.mdx_get_forces_noalloc.argtypes = [vp, fp]
     L.mdx_get_energies.argtypes = [vp, dp]
     L.mdx_get_virial.argtypes = [vp, dp, dp]
     L.mdx_step.argtypes = [vp, ctypes.c_longlong]
@@ -406,6 +407,12 @@ class Engine:
         f = np.zeros((self.n, 3), np.float32)
         self._call("mdx_get_forces", _p(f, ctypes.c_float))
         return f, self.energies()
+
+    def forces(self, noalloc=False):
+        """Forces of the last compute(); noalloc=True goes through the entry point that stages in fixed scratch."""
+        f = np.zeros((self.n, 3), np.float32)
+        self._call("mdx_get_forces_noalloc" if noalloc else "mdx_get_forces", _p(f, ctypes.c_float))
+        return f
 
     def energies(self):
         e = np.zeros(E_N, np.float64)
