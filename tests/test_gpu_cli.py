@@ -114,6 +114,9 @@ def test_restart_from_checkpoint_appends(chain):
     r = run(["mdrun", "-deffnm", "md", "-cpi", "md.cpt"], d)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "continuing from step 200" in r.stdout
+    with open(os.path.join(d, "md.log")) as f:
+        assert "Restored the coupling and pull state from the checkpoint" in f.read()
+    assert len(tpr.load_checkpoint(os.path.join(d, "md.cpt"))["extra"]["run_state"]) == 64
     fr = traj.read_xtc(os.path.join(d, "md.xtc"))
     steps = [f["step"] for f in fr]
     assert steps == list(range(0, 401, 10))               # no duplicate of the frame at the restart step

@@ -231,3 +231,56 @@ def test_minimizer_first_point_matches_oracle(small_complex):
     fmax = float(np.sqrt(((ref["f"] + fpr) ** 2).sum(1)).max())
     assert abs(res["fmax0"] - fmax) < 1e-4 * fmax
     assert res["steps"] == 0 and res["status"] == 0
+
+
+def test_restart_carries_coupling_and_pull_state(small_complex):
+    """`gmx mdrun -cpi` (/root/reference/scripts/run_smd_with_recovery.py:144-156): a run stopped half way and
+    continued from (x, v, box, step, run state) follows the uninterrupted run: the umbrella reference keeps moving
+    from its original start (no jump by rate * t), the pull work carries on, the Parrinello-Rahman box velocity and
+    the thermostat factors are those of the interrupted run."""
+    s = small_complex
+    kw = dict(rc=1.0, dt=0.002, nstcalcenergy=10, tc_groups=["Protein", "Non-Protein"], ref_t=[300.0, 300.0], tau_t=[0.1, 0.1],
+              nsttcouple=10, pcoupl=2, tau_p=1.0, ref_p=1.0, compressibility=4.5e-5, nstpcouple=10, seed=5, dispcorr=2)
+    pull = dict(type="umbrella", k=1000.0, rate=-0.5, nstout=5, start=True)
+    n_half = 20
+
+    a = eng.Engine(s, **kw)
+    a.set_pull(s.groups["ActiveSite"], s.groups["MOL"], **pull)
+    a.step(2 * n_half)
+    rec_a = a.pop_pull_records(); rs_a = a.get_run_state(); _, _, box_a = a.get_state(); a.close()
+
+    b = eng.Engine(s, **kw)
+    b.set_pull(s.groups["ActiveSite"], s.groups["MOL"], **pull)
+    b.step(n_half)
+    rec_1 = b.pop_pull_records(); rs = b.get_run_state(); x, v, box = b.get_state(); b.close()
+    assert rs[eng.RS["PULL_HAVE_INIT"]] == 1.0 and abs(rs[eng.RS["PR_BOXV"]]) > 0
+
+    c = eng.Engine(_with(_box(s, box), x, v), **kw)
+    c.set_step(n_half)
+    c.set_pull(s.groups["ActiveSite"], s.groups["MOL"], **pull)
+    c.set_run_state(rs)
+    rs_back = c.get_run_state()
+    for key, n in (("LAMBDA", 8), ("THERM_INTEGRAL", 8), ("PR_BOXV", 9), ("PULL_INIT", 1), ("PULL_WORK", 1), ("BARO_INTEGRAL", 1)):
+        o = eng.RS[key]
+        assert np.array_equal(rs_back[o:o + n], rs[o:o + n]), key
+    c.step(n_half)
+    rec_2 = c.pop_pull_records(); rs_c = c.get_run_state(); _, _, box_c = c.get_state(); c.close()
+
+    rec_b = np.concatenate([rec_1, rec_2])
+    assert rec_b.shape == rec_a.shape and np.allclose(rec_b[:, 0], rec_a[:, 0], atol=1e-9)
+    # the two trajectories differ by rounding only (float atomics, float32 box in the restart)
+    assert np.abs(rec_b[:, 1] - rec_a[:, 1]).max() < 2e-5
+    assert np.abs(rec_b[:, 2] - rec_a[:, 2]).max() < 1000.0 * 2e-5 + 1e-3          # a reference re-seeded at the restart would be off by k rate t = 20
+    assert np.abs(rec_b[:, 3] - rec_a[:, 3]).max() < 1e-3 + 1e-3 * np.abs(rec_a[:, 3]).max()
+    assert abs(rs_c[eng.RS["PULL_INIT"]] - rs_a[eng.RS["PULL_INIT"]]) < 1e-12
+    bv_a, bv_c = rs_a[eng.RS["PR_BOXV"]:eng.RS["PR_BOXV"] + 9], rs_c[eng.RS["PR_BOXV"]:eng.RS["PR_BOXV"] + 9]
+    assert np.abs(bv_c - bv_a).max() < 2e-3 * np.abs(bv_a).max()
+    assert np.abs(box_c - box_a).max() < 1e-6
+    la, lc = rs_a[eng.RS["LAMBDA"]:eng.RS["LAMBDA"] + 2], rs_c[eng.RS["LAMBDA"]:eng.RS["LAMBDA"] + 2]
+    assert np.abs(lc - la).max() < 1e-5
+
+
+def _box(s, box):
+    t = copy.copy(s)
+    t.box = np.asarray(box, dtype=np.float64)
+    return t

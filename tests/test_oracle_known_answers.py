@@ -221,3 +221,76 @@ def test_pull_distance_across_boundary():
     r, u, _, _ = R.pull_distance(xs, box, m, np.arange(10), np.arange(10, 16))
     assert abs(r - np.linalg.norm(com2 - com1)) < 1e-12
     assert np.allclose(u, (com2 - com1) / r)
+
+
+# ------------------------------------------------------------------ random streams and coupling restatements
+def test_philox_known_answer_vectors():
+    """Philox4x32-10 against the known-answer vectors published with the Random123 library (kat_vectors)."""
+    from oracle import mdref as R
+    kat = [((0, 0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffffffffffff, 0xffffffffffffffff, 0xffffffffffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x85a308d3243f6a88, 0x0370734413198a2e, 0x299f31d0a4093822), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for (lo, hi, key), want in kat:
+        assert tuple(int(w) for w in R.philox4x32(lo, hi, key)) == want
+
+
+def test_rng_stream_moments():
+    from oracle import mdref as R
+    r = R.RngStream(123, R.STREAM_TCOUPLE, 0)
+    g = np.array([r.gauss() for _ in range(4000)])
+    assert abs(g.mean()) < 0.06 and abs(g.std() - 1.0) < 0.04
+    c = np.array([R.RngStream(5, 1, k).chi2(500.0) for k in range(400)])
+    assert abs(c.mean() - 500.0) < 6.0 and abs(c.std() - np.sqrt(1000.0)) < 4.0
+    # a different step, stream or seed gives a different draw; the same triple the same
+    assert R.RngStream(1, 2, 3).gauss() == R.RngStream(1, 2, 3).gauss()
+    assert len({R.RngStream(1, 2, 3).gauss(), R.RngStream(1, 2, 4).gauss(), R.RngStream(1, 3, 3).gauss(), R.RngStream(2, 2, 3).gauss()}) == 4
+
+
+def test_generated_velocities_exact_temperature_no_drift():
+    from oracle import mdref as R
+    rng = np.random.default_rng(0)
+    m = rng.choice([1.008, 12.011, 15.9994], size=3000)
+    v = R.generate_velocities(m, 300.0, 99)
+    assert abs(2 * 0.5 * (m[:, None] * v * v).sum() / (3 * len(m) * R.BOLTZ) - 300.0) < 1e-4        # masses enter as float32 inverses
+    assert np.abs((m[:, None] * v).sum(0) / m.sum()).max() < 1e-6
+    z = v / np.sqrt(R.BOLTZ * 300.0 / m)[:, None]
+    assert abs(z.std() - 1.0) < 0.03
+
+
+def test_vrescale_relaxes_to_reference_energy():
+    """Deterministic part of V-rescale: with the noise switched off (r1 = 0, chi^2 at its mean) the kinetic energy
+    relaxes to the reference exponentially with tau_t."""
+    from oracle import mdref as R
+    ndf, ekref, tau, dt = 3000.0, 0.5 * 3000.0 * R.BOLTZ * 300.0, 0.1, 0.002
+    ek = 2.0 * ekref
+    for _ in range(50):
+        ek = R.vrescale_new_ekin(ek, ekref, ndf, dt, tau, 0.0, ndf)
+    assert abs((ek - ekref) / ekref - np.exp(-50 * dt / tau)) < 1e-12
+
+
+def test_parrinello_rahman_period_is_tau_p():
+    """With W^-1 = 4 pi^2 beta / (3 tau_p^2 L) a box whose pressure answers volume changes through the
+    compressibility, P = P_ref - (V - V0) / (beta V0), oscillates with period tau_p: the defining property of the
+    coupling-mass convention. Checked in a cubic and in a rhombic dodecahedral cell."""
+    from oracle import mdref as R
+    beta, tau_p, dt = 4.5e-5, 2.0, 0.002
+    for box0 in (np.diag([4.0, 4.0, 4.0]), np.array([[5.0, 0, 0], [0, 5.0, 0], [2.5, 2.5, 5.0 * np.sqrt(2) / 2]])):
+        v0 = abs(np.linalg.det(box0))
+        box = box0 * 1.002
+        boxv = np.zeros((3, 3))
+        ls = []
+        for _ in range(int(2.5 * tau_p / dt)):
+            p = 1.0 - (abs(np.linalg.det(box)) - v0) / (beta * v0)
+            box, boxv, mu, M = R.parrinello_rahman_step(box, boxv, p * np.eye(3), 1.0, beta, tau_p, dt)
+            ls.append(box[0, 0])
+            assert abs(M[0, 0] - 2.0 * boxv[0, 0] / (box[0, 0] / mu)) < 1e-12
+        ls = np.array(ls) - box0[0, 0]
+        down = np.nonzero((ls[:-1] > 0) & (ls[1:] <= 0))[0]            # downward zero crossings, one per period
+        assert len(down) >= 2
+        period = (down[1] - down[0]) * dt
+        # exactly tau_p for the cube; in a cell with unequal diagonal elements the rule's own geometry factor
+        # V sum_d (1 / b_dd^2) / (3 L_max) enters (0.943 for the dodecahedron: period 1.03 tau_p)
+        geo = v0 * sum(1.0 / box0[d, d] ** 2 for d in range(3)) / (3.0 * box0.diagonal().max())
+        assert abs(period - tau_p / np.sqrt(geo)) < 0.005 * tau_p, period
+        # every element keeps its ratio to b_xx (isotropic scaling preserves the cell shape)
+        assert np.abs(box / box[0, 0] - box0 / box0[0, 0]).max() < 1e-12
