@@ -22,6 +22,7 @@
 #include <limits.h>
 #include <math.h>
 #include <vector>
+#include <thread>
 
 extern "C" {
 
@@ -53,6 +54,31 @@ struct BitWriter {
         nacc += nbits;
         while (nacc >= 8) { buf[len++] = (unsigned char)(acc >> (nacc - 8)); nacc -= 8; }
         acc &= (1ull << nacc) - 1ull;
+    }
+    // append the bit string of another writer, its pending bits included (the other writer stays usable)
+    void append(const BitWriter &o)
+    {
+        if (buf.size() < len + o.len + 16) buf.resize(len + o.len + 16);
+        if (nacc == 0) {
+            memcpy(buf.data() + len, o.buf.data(), o.len);
+            len += o.len;
+        } else {
+            // the source bytes shifted right by the nacc pending bits, eight at a time
+            const int sh = nacc;
+            uint64_t carry = acc;                       // low `sh` bits pending
+            size_t k = 0;
+            unsigned char *dst = buf.data() + len;
+            for (; k + 8 <= o.len; k += 8) {
+                uint64_t v; memcpy(&v, o.buf.data() + k, 8); v = __builtin_bswap64(v);
+                const uint64_t out = (carry << (64 - sh)) | (v >> sh);
+                const uint64_t be = __builtin_bswap64(out);
+                memcpy(dst + k, &be, 8);
+                carry = v & ((1ull << sh) - 1ull);
+            }
+            len += k; acc = carry;
+            for (; k < o.len; k++) put(8, o.buf[k]);
+        }
+        if (o.nacc > 0) put(o.nacc, (unsigned)o.acc);
     }
     size_t finish()
     {
@@ -149,9 +175,122 @@ static void xdr_put_f32(std::vector<unsigned char> &o, float f) { uint32_t u; me
 static uint32_t be32(const unsigned char *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 static float bef32(const unsigned char *p) { uint32_t u = be32(p); float f; memcpy(&f, &u, 4); return f; }
 
+}  // extern "C" (templates have C++ linkage)
+// fn(k) for k = 0 .. T-1, k = 0 on the calling thread and the others on threads started for the call (tens of
+// microseconds each, against milliseconds per frame; no pool whose idle workers would spin next to the step loop)
+template <typename F>
+static void run_slices(int T, F fn)
+{
+    if (T <= 1) { fn(0); return; }
+    std::vector<std::thread> th;
+    th.reserve(T - 1);
+    for (int k = 1; k < T; k++) th.emplace_back([&fn, k] { fn(k); });
+    fn(0);
+    for (std::thread &t : th) t.join();
+}
+extern "C" {
+
+// segments of multi-threaded frames that had to be encoded again from the true state (diagnostic counter)
+static long long g_xtc_respeculated = 0;
+static int g_xtc_warm = 2048;      // atoms a segment's thread walks through, without output, ahead of its segment
+
+// ---------------------------------------------------------------- xtc run encoder
+// Frame-wide constants of the coordinate block.
+struct XtcParams {
+    int minint[3];
+    unsigned int sizeint[3], bitsizeint[3];
+    int bitsize;
+    int minidx, maxidx, larger;
+};
+// What the encoder carries from one run of atoms to the next.
+struct XtcState {
+    int i;              // next atom
+    int smallidx;       // current entry of the small-number table
+    int smallnum, smaller;   // half the table entry, and half the entry below (history dependent at the table's lower end)
+    int prevrun;        // length code of the last run header written
+    int prev[3];        // last atom sent
+    bool operator==(const XtcState &o) const
+    {
+        return i == o.i && smallidx == o.smallidx && smallnum == o.smallnum && smaller == o.smaller && prevrun == o.prevrun &&
+               prev[0] == o.prev[0] && prev[1] == o.prev[1] && prev[2] == o.prev[2];
+    }
+};
+
+// Encode whole runs starting at atom st.i until st.i >= stop (a run is never cut, so st.i may end beyond stop).
+// With w == nullptr only the state is advanced. The integer coordinates are not modified: the interchange of the
+// first two atoms of a run is done on the fly.
+static void xtc_encode_range(const int *ip, int natoms, const XtcParams &P, XtcState &st, int stop, BitWriter *w)
+{
+    int i = st.i, smallidx = st.smallidx, prevrun = st.prevrun;
+    int prev[3] = { st.prev[0], st.prev[1], st.prev[2] };
+    int smaller = st.smaller, smallnum = st.smallnum;
+    unsigned int sizesmall[3] = { (unsigned)kMagic[smallidx], (unsigned)kMagic[smallidx], (unsigned)kMagic[smallidx] };
+    unsigned int tmp[30];
+    while (i < stop && i < natoms) {
+        const int *c = ip + 3 * (size_t)i;
+        bool is_small = false;
+        int is_smaller;
+        if (smallidx < P.maxidx && i >= 1 && abs(c[0] - prev[0]) < P.larger && abs(c[1] - prev[1]) < P.larger && abs(c[2] - prev[2]) < P.larger)
+            is_smaller = 1;
+        else if (smallidx > P.minidx)
+            is_smaller = -1;
+        else
+            is_smaller = 0;
+        // a second atom close to the first: the two are interchanged (the second is sent in full, the first as the
+        // run's first small difference), which keeps a water's oxygen-hydrogen differences small
+        const int *first = c, *second = nullptr;
+        if (i + 1 < natoms && abs(c[0] - c[3]) < smallnum && abs(c[1] - c[4]) < smallnum && abs(c[2] - c[5]) < smallnum) {
+            first = c + 3; second = c;
+            is_small = true;
+        }
+        if (w) {
+            unsigned int big[3] = { (unsigned)(first[0] - P.minint[0]), (unsigned)(first[1] - P.minint[1]), (unsigned)(first[2] - P.minint[2]) };
+            if (P.bitsize == 0) { w->put(P.bitsizeint[0], big[0]); w->put(P.bitsizeint[1], big[1]); w->put(P.bitsizeint[2], big[2]); }
+            else put_triple(*w, P.bitsize, P.sizeint, big);
+        }
+        prev[0] = first[0]; prev[1] = first[1]; prev[2] = first[2];
+        i++;
+        int run = 0;
+        if (!is_small && is_smaller == -1) is_smaller = 0;
+        while (is_small && run < 8 * 3) {
+            const int *cur = second ? second : ip + 3 * (size_t)i;
+            second = nullptr;
+            if (is_smaller == -1) {
+                const long long dx = cur[0] - prev[0], dy = cur[1] - prev[1], dz = cur[2] - prev[2];
+                if (dx * dx + dy * dy + dz * dz >= (long long)smaller * smaller) is_smaller = 0;
+            }
+            tmp[run++] = (unsigned)(cur[0] - prev[0] + smallnum);
+            tmp[run++] = (unsigned)(cur[1] - prev[1] + smallnum);
+            tmp[run++] = (unsigned)(cur[2] - prev[2] + smallnum);
+            prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2];
+            i++;
+            is_small = false;
+            if (i < natoms) {
+                const int *nx = ip + 3 * (size_t)i;
+                if (abs(nx[0] - prev[0]) < smallnum && abs(nx[1] - prev[1]) < smallnum && abs(nx[2] - prev[2]) < smallnum) is_small = true;
+            }
+        }
+        if (run != prevrun || is_smaller != 0) {
+            prevrun = run;
+            if (w) { w->put(1, 1); w->put(5, (unsigned)(run + is_smaller + 1)); }
+        } else if (w) {
+            w->put(1, 0);
+        }
+        if (w) for (int k = 0; k < run; k += 3) put_triple(*w, smallidx, sizesmall, &tmp[k]);
+        if (is_smaller != 0) {
+            smallidx += is_smaller;
+            if (is_smaller < 0) { smallnum = smaller; smaller = kMagic[smallidx - 1] / 2; }
+            else { smaller = smallnum; smallnum = kMagic[smallidx] / 2; }
+            sizesmall[0] = sizesmall[1] = sizesmall[2] = (unsigned)kMagic[smallidx];
+        }
+    }
+    st.i = i; st.smallidx = smallidx; st.smallnum = smallnum; st.smaller = smaller; st.prevrun = prevrun;
+    st.prev[0] = prev[0]; st.prev[1] = prev[1]; st.prev[2] = prev[2];
+}
+
 // ---------------------------------------------------------------- xtc coordinate block
 // Appends `natoms` (int), and the raw or compressed coordinates to `o`.
-static int xtc_encode_coords(std::vector<unsigned char> &o, int natoms, const float *x, float precision)
+static int xtc_encode_coords(std::vector<unsigned char> &o, int natoms, const float *x, float precision, int nthreads)
 {
     xdr_put_u32(o, (uint32_t)natoms);
     if (natoms <= 9) {
@@ -165,20 +304,39 @@ static int xtc_encode_coords(std::vector<unsigned char> &o, int natoms, const fl
     if (ip_scratch.size() < 3 * (size_t)natoms + 3) ip_scratch.resize(3 * (size_t)natoms + 3);
     int *const ip = ip_scratch.data();
     int minint[3] = { INT_MAX, INT_MAX, INT_MAX }, maxint[3] = { INT_MIN, INT_MIN, INT_MIN };
-    int mindiff = INT_MAX, old[3] = { 0, 0, 0 };
-    for (int i = 0; i < natoms; i++) {
-        int l[3];
-        for (int d = 0; d < 3; d++) {
-            const float lf = x[3 * i + d] * precision;
-            if (!(fabsf(lf) <= kMaxAbs)) return TRJ_ERR_RANGE;       // also catches NaN
-            l[d] = (int)(lf >= 0 ? lf + 0.5f : lf - 0.5f);
-            if (l[d] < minint[d]) minint[d] = l[d];
-            if (l[d] > maxint[d]) maxint[d] = l[d];
-            ip[3 * (size_t)i + d] = l[d];
+    int mindiff = INT_MAX;
+    {
+        // rounding to integers, extent and the smallest neighbour distance: independent slices of atoms
+        const int TQ = (nthreads > 1 && natoms >= 8192) ? (nthreads > 16 ? 16 : nthreads) : 1;
+        int mn[16][3], mx[16][3], md[16], bad[16];
+        run_slices(TQ, [&](int k) {
+            const int b0 = (int)((long long)natoms * k / TQ), b1 = (int)((long long)natoms * (k + 1) / TQ);
+            int lmn[3] = { INT_MAX, INT_MAX, INT_MAX }, lmx[3] = { INT_MIN, INT_MIN, INT_MIN }, lmd = INT_MAX, lbad = 0;
+            int old[3] = { 0, 0, 0 };
+            if (b0 > 0)
+                for (int d = 0; d < 3; d++) { const float lf = x[3 * (size_t)(b0 - 1) + d] * precision; old[d] = (int)(lf >= 0 ? lf + 0.5f : lf - 0.5f); }
+            for (int i = b0; i < b1; i++) {
+                int l[3];
+                for (int d = 0; d < 3; d++) {
+                    const float lf = x[3 * (size_t)i + d] * precision;
+                    if (!(fabsf(lf) <= kMaxAbs)) { lbad = 1; l[d] = 0; continue; }       // also catches NaN
+                    l[d] = (int)(lf >= 0 ? lf + 0.5f : lf - 0.5f);
+                    if (l[d] < lmn[d]) lmn[d] = l[d];
+                    if (l[d] > lmx[d]) lmx[d] = l[d];
+                    ip[3 * (size_t)i + d] = l[d];
+                }
+                const long long diff = llabs((long long)old[0] - l[0]) + llabs((long long)old[1] - l[1]) + llabs((long long)old[2] - l[2]);
+                if (i > 0 && diff < lmd) lmd = (int)diff;
+                old[0] = l[0]; old[1] = l[1]; old[2] = l[2];
+            }
+            for (int d = 0; d < 3; d++) { mn[k][d] = lmn[d]; mx[k][d] = lmx[d]; }
+            md[k] = lmd; bad[k] = lbad;
+        });
+        for (int k = 0; k < TQ; k++) {
+            if (bad[k]) return TRJ_ERR_RANGE;
+            for (int d = 0; d < 3; d++) { if (mn[k][d] < minint[d]) minint[d] = mn[k][d]; if (mx[k][d] > maxint[d]) maxint[d] = mx[k][d]; }
+            if (md[k] < mindiff) mindiff = md[k];
         }
-        const long long diff = llabs((long long)old[0] - l[0]) + llabs((long long)old[1] - l[1]) + llabs((long long)old[2] - l[2]);
-        if (i > 0 && diff < mindiff) mindiff = (int)diff;
-        old[0] = l[0]; old[1] = l[1]; old[2] = l[2];
     }
     for (int d = 0; d < 3; d++) xdr_put_u32(o, (uint32_t)minint[d]);
     for (int d = 0; d < 3; d++) xdr_put_u32(o, (uint32_t)maxint[d]);
@@ -195,72 +353,66 @@ static int xtc_encode_coords(std::vector<unsigned char> &o, int natoms, const fl
     int smallidx = kFirstIdx;
     while (smallidx < kLastIdx - 1 && kMagic[smallidx] < mindiff) smallidx++;
     xdr_put_u32(o, (uint32_t)smallidx);
+    XtcParams P;
+    for (int d = 0; d < 3; d++) { P.minint[d] = minint[d]; P.sizeint[d] = sizeint[d]; P.bitsizeint[d] = bitsizeint[d]; }
+    P.bitsize = bitsize;
     // the table's last entry bounds both indices (frames with > 16777216 between all neighbours)
-    const int maxidx = (kLastIdx - 1 < smallidx + 8) ? kLastIdx - 1 : smallidx + 8;
-    const int minidx = maxidx - 8;
-    int smaller = kMagic[(kFirstIdx > smallidx - 1) ? kFirstIdx : smallidx - 1] / 2;
-    int smallnum = kMagic[smallidx] / 2;
-    unsigned int sizesmall[3] = { (unsigned)kMagic[smallidx], (unsigned)kMagic[smallidx], (unsigned)kMagic[smallidx] };
-    const int larger = kMagic[maxidx] / 2;
+    P.maxidx = (kLastIdx - 1 < smallidx + 8) ? kLastIdx - 1 : smallidx + 8;
+    P.minidx = P.maxidx - 8;
+    P.larger = kMagic[P.maxidx] / 2;
+    XtcState st0;
+    st0.i = 0; st0.smallidx = smallidx; st0.prevrun = -1; st0.prev[0] = st0.prev[1] = st0.prev[2] = 0;
+    st0.smaller = kMagic[(kFirstIdx > smallidx - 1) ? kFirstIdx : smallidx - 1] / 2;
+    st0.smallnum = kMagic[smallidx] / 2;
     static thread_local std::vector<unsigned char> bits_scratch;
     BitWriter w;
     w.buf.swap(bits_scratch);
     w.reserve_bytes((size_t)natoms * 16 + 64);     // > 3 x 32 bits + run flags per atom
-    int prev[3] = { 0, 0, 0 };
-    int prevrun = -1;
-    int i = 0;
-    int *c = ip;
-    unsigned int tmp[30];
-    while (i < natoms) {
-        bool is_small = false;
-        int is_smaller;
-        if (smallidx < maxidx && i >= 1 && abs(c[0] - prev[0]) < larger && abs(c[1] - prev[1]) < larger && abs(c[2] - prev[2]) < larger)
-            is_smaller = 1;
-        else if (smallidx > minidx)
-            is_smaller = -1;
-        else
-            is_smaller = 0;
-        if (i + 1 < natoms) {
-            if (abs(c[0] - c[3]) < smallnum && abs(c[1] - c[4]) < smallnum && abs(c[2] - c[5]) < smallnum) {
-                // interchange the first with the second atom of the run
-                for (int d = 0; d < 3; d++) { const int t = c[d]; c[d] = c[3 + d]; c[3 + d] = t; }
-                is_small = true;
+    const int T = (nthreads > 1 && natoms >= 8192) ? (nthreads > 16 ? 16 : nthreads) : 1;
+    if (T == 1) {
+        xtc_encode_range(ip, natoms, P, st0, natoms, &w);
+    } else {
+        // Speculative segments: thread k > 0 runs the encoder's state machine, without output, over the kWarm atoms
+        // ahead of its segment (the adaptive small-number index and the run boundaries settle within a few hundred
+        // atoms whatever they started from), then encodes its segment. A segment is kept when the state its
+        // predecessor really ended in is the state it assumed; otherwise it is encoded again from the true state, so
+        // the bytes are those of the one-thread encoder in every case.
+        const int kWarm = g_xtc_warm;
+        long long respeculated = 0;
+        std::vector<XtcState> assumed(T), ended(T);
+        static thread_local std::vector<BitWriter> segw;
+        if ((int)segw.size() < T) segw.resize(T);
+        for (int k = 1; k < T; k++) { segw[k].len = 0; segw[k].acc = 0; segw[k].nacc = 0; segw[k].reserve_bytes(((size_t)natoms / T + 64) * 16 + 64); }
+        BitWriter *const seg = segw.data();        // (a thread_local name inside the parallel region would mean each worker's own, empty, vector)
+        BitWriter *const w0 = &w;
+        run_slices(T, [&](int k) {
+            const int b0 = (int)((long long)natoms * k / T), b1 = (k + 1 == T) ? natoms : (int)((long long)natoms * (k + 1) / T);
+            XtcState st = st0;
+            if (k > 0) {
+                st.i = b0 > kWarm ? b0 - kWarm : 0;
+                if (st.i > 0) { st.prev[0] = ip[3 * (size_t)(st.i - 1)]; st.prev[1] = ip[3 * (size_t)(st.i - 1) + 1]; st.prev[2] = ip[3 * (size_t)(st.i - 1) + 2]; }
+                xtc_encode_range(ip, natoms, P, st, b0, nullptr);
+            }
+            assumed[k] = st;
+            xtc_encode_range(ip, natoms, P, st, b1, k == 0 ? w0 : &seg[k]);
+            ended[k] = st;
+        });
+        for (int k = 1; k < T; k++) {
+            const int b1 = (k + 1 == T) ? natoms : (int)((long long)natoms * (k + 1) / T);
+            if (ended[k - 1].i >= b1 && k + 1 < T) {       // the predecessor ran past this whole segment (one long run): nothing of it is left
+                ended[k] = ended[k - 1];
+                continue;
+            }
+            if (ended[k - 1] == assumed[k]) {
+                w.append(seg[k]);
+            } else {
+                respeculated++;
+                XtcState st = ended[k - 1];
+                xtc_encode_range(ip, natoms, P, st, b1, &w);
+                ended[k] = st;
             }
         }
-        unsigned int big[3] = { (unsigned)(c[0] - minint[0]), (unsigned)(c[1] - minint[1]), (unsigned)(c[2] - minint[2]) };
-        if (bitsize == 0) { w.put(bitsizeint[0], big[0]); w.put(bitsizeint[1], big[1]); w.put(bitsizeint[2], big[2]); }
-        else put_triple(w, bitsize, sizeint, big);
-        prev[0] = c[0]; prev[1] = c[1]; prev[2] = c[2];
-        c += 3; i++;
-        int run = 0;
-        if (!is_small && is_smaller == -1) is_smaller = 0;
-        while (is_small && run < 8 * 3) {
-            if (is_smaller == -1) {
-                const long long dx = c[0] - prev[0], dy = c[1] - prev[1], dz = c[2] - prev[2];
-                if (dx * dx + dy * dy + dz * dz >= (long long)smaller * smaller) is_smaller = 0;
-            }
-            tmp[run++] = (unsigned)(c[0] - prev[0] + smallnum);
-            tmp[run++] = (unsigned)(c[1] - prev[1] + smallnum);
-            tmp[run++] = (unsigned)(c[2] - prev[2] + smallnum);
-            prev[0] = c[0]; prev[1] = c[1]; prev[2] = c[2];
-            i++; c += 3;
-            is_small = false;
-            if (i < natoms && abs(c[0] - prev[0]) < smallnum && abs(c[1] - prev[1]) < smallnum && abs(c[2] - prev[2]) < smallnum) is_small = true;
-        }
-        if (run != prevrun || is_smaller != 0) {
-            prevrun = run;
-            w.put(1, 1);
-            w.put(5, (unsigned)(run + is_smaller + 1));
-        } else {
-            w.put(1, 0);
-        }
-        for (int k = 0; k < run; k += 3) put_triple(w, smallidx, sizesmall, &tmp[k]);
-        if (is_smaller != 0) {
-            smallidx += is_smaller;
-            if (is_smaller < 0) { smallnum = smaller; smaller = kMagic[smallidx - 1] / 2; }
-            else { smaller = smallnum; smallnum = kMagic[smallidx] / 2; }
-            sizesmall[0] = sizesmall[1] = sizesmall[2] = (unsigned)kMagic[smallidx];
-        }
+        g_xtc_respeculated += respeculated;
     }
     const size_t nbytes = w.finish();
     xdr_put_u32(o, (uint32_t)nbytes);
@@ -274,8 +426,9 @@ static int xtc_encode_coords(std::vector<unsigned char> &o, int natoms, const fl
 // cap must be at least trj_xtc_frame_bound(natoms).
 long long trj_xtc_frame_bound(int natoms) { return 128 + (long long)natoms * 16; }
 
-long long trj_xtc_encode_frame(unsigned char *out, long long cap, int natoms, long long step, float time, const float *box9,
-                               const float *x, float precision)
+// nthreads > 1 encodes segments of a large frame on that many threads (same bytes as one thread).
+long long trj_xtc_encode_frame_mt(unsigned char *out, long long cap, int natoms, long long step, float time, const float *box9,
+                                  const float *x, float precision, int nthreads)
 {
     std::vector<unsigned char> o;
     o.reserve((size_t)natoms * 5 + 128);
@@ -284,11 +437,17 @@ long long trj_xtc_encode_frame(unsigned char *out, long long cap, int natoms, lo
     xdr_put_u32(o, (uint32_t)(int32_t)step);
     xdr_put_f32(o, time);
     for (int k = 0; k < 9; k++) xdr_put_f32(o, box9[k]);
-    const int rc = xtc_encode_coords(o, natoms, x, precision);
+    const int rc = xtc_encode_coords(o, natoms, x, precision, nthreads);
     if (rc != TRJ_OK) return rc;
     if ((long long)o.size() > cap) return TRJ_ERR_RANGE;
     memcpy(out, o.data(), o.size());
     return (long long)o.size();
+}
+
+long long trj_xtc_encode_frame(unsigned char *out, long long cap, int natoms, long long step, float time, const float *box9,
+                               const float *x, float precision)
+{
+    return trj_xtc_encode_frame_mt(out, cap, natoms, step, time, box9, x, precision, 1);
 }
 
 int trj_xtc_append(const char *path, int truncate, int natoms, long long step, float time, const float *box9, const float *x,
@@ -489,6 +648,11 @@ int trj_trr_decode_frame(const unsigned char *data, long long len, long long *us
     return TRJ_OK;
 }
 
-int trj_version(void) { return 1; }
+long long trj_xtc_respeculated(void) { return g_xtc_respeculated; }
+// Test hook: length of the warm-up walk (0 makes nearly every segment start from a wrong guess, which exercises the
+// path that encodes a segment again from the true state). Returns the previous value.
+int trj_xtc_set_warmup(int atoms) { const int old = g_xtc_warm; g_xtc_warm = atoms < 0 ? 0 : atoms; return old; }
+
+int trj_version(void) { return 2; }
 
 }  // extern "C"

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libmdxio.so")
-SYMBOLS = ["trj_version", "trj_xtc_frame_bound", "trj_xtc_encode_frame", "trj_xtc_append", "trj_xtc_decode_frame",
+SYMBOLS = ["trj_version", "trj_xtc_frame_bound", "trj_xtc_encode_frame", "trj_xtc_encode_frame_mt", "trj_xtc_respeculated", "trj_xtc_set_warmup", "trj_xtc_append", "trj_xtc_decode_frame",
            "trj_trr_frame_bound", "trj_trr_encode_frame", "trj_trr_append", "trj_trr_decode_frame"]
 _LIB = None
 
@@ -34,6 +34,9 @@ def load_library():
     L.trj_xtc_frame_bound.restype = c_ll; L.trj_xtc_frame_bound.argtypes = [c_int]
     L.trj_xtc_encode_frame.restype = c_ll
     L.trj_xtc_encode_frame.argtypes = [ucp, c_ll, c_int, c_ll, c_f, fp, fp, c_f]
+    L.trj_xtc_encode_frame_mt.restype = c_ll
+    L.trj_xtc_encode_frame_mt.argtypes = [ucp, c_ll, c_int, c_ll, c_f, fp, fp, c_f, c_int]
+    L.trj_xtc_respeculated.restype = c_ll
     L.trj_xtc_append.argtypes = [ctypes.c_char_p, c_int, c_int, c_ll, c_f, fp, fp, c_f]
     L.trj_xtc_decode_frame.argtypes = [ucp, c_ll, ctypes.POINTER(c_ll), ctypes.POINTER(c_int), ctypes.POINTER(c_ll),
                                        fp, fp, fp, fp]
@@ -58,8 +61,10 @@ def _f32(a):
 
 
 class XtcWriter:
-    def __init__(self, path: str, natoms: int, precision: float = 1000.0, append: bool = False):
+    def __init__(self, path: str, natoms: int, precision: float = 1000.0, append: bool = False, threads: int = 1):
+        """threads > 1: large frames are encoded in segments on that many threads (byte-identical output)."""
         self.lib = load_library()
+        self.threads = max(1, int(threads))
         self.natoms = int(natoms)
         self.precision = float(precision)
         self.f = open(path, "ab" if append else "wb")
@@ -76,7 +81,8 @@ class XtcWriter:
         buf = getattr(tl, "buf", None)
         if buf is None:
             buf = tl.buf = (ctypes.c_ubyte * int(self.lib.trj_xtc_frame_bound(self.natoms)))()
-        n = self.lib.trj_xtc_encode_frame(buf, len(buf), self.natoms, int(step), float(time), _fptr(box), _fptr(x), self.precision)
+        n = self.lib.trj_xtc_encode_frame_mt(buf, len(buf), self.natoms, int(step), float(time), _fptr(box), _fptr(x), self.precision,
+                                             self.threads)
         if n < 0:
             raise TrajError(f"xtc encoding failed ({n}): coordinate out of range or not finite")
         return bytes(memoryview(buf)[:n])

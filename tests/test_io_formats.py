@@ -426,3 +426,91 @@ def test_mdrun_fails_loudly_without_run_input(tmp_path):
     err = io.StringIO()
     assert runner.mdrun(["-deffnm", str(tmp_path / "nothing")], out=io.StringIO(), err=err) == 1
     assert "does not exist" in err.getvalue()
+
+
+# ------------------------------------------------------------------ xtc bytes pinned independently of the package's decoder
+_WATER12 = [(0.512, 1.203, 0.877), (1.934, 0.321, 2.105), (2.467, 2.250, 0.139), (0.048, 2.911, 1.660)]
+_WATER12_HEX = (
+    "000007cb0000000c000000073c656042"                      # magic 1995, 12 atoms, step 7, t = 0.014
+    "404000000000000000000000" "000000004040000000000000" "000000000000000040400000"      # box 3 nm cube
+    "0000000c447a0000"                                      # 12 atoms again, precision 1000
+    "00000018000001410000007f"                              # minint  24, 321, 127 (smallest x, y, z in pm)
+    "000009ef00000bbc00000858"                              # maxint 2543, 3004, 2136
+    "00000016"                                              # smallidx 22: smallest neighbour distance sum|d| = 146 -> first table entry >= 146 is 161
+    "0000002c"                                              # 44 bytes of bit stream
+    "3a9a78b52436a3074f354654890b3279fa9f6f6879f82b1b6cf3d2adb7b43cfc158a08e3c900dbda1e7e0ac4")
+
+
+def _water12():
+    x = []
+    for (a, b, c) in _WATER12:
+        x += [(a, b, c), (a + 0.076, b + 0.058, c - 0.012), (a - 0.024, b + 0.093, c + 0.031)]
+    return x
+
+
+def test_xtc_bytes_of_a_twelve_atom_frame():
+    """Four water-like triples: the header fields are worked out by hand (comments next to the hex above), the bit
+    stream comes from the independent restatement of the format in tests/xtc3_reference.py (byte-array arithmetic as
+    in the published xdrfile description); the C encoder has to produce exactly these bytes."""
+    import xtc3_reference as X
+    from mdx.io import traj
+    box = [3.0, 0, 0, 0, 3.0, 0, 0, 0, 3.0]
+    want = bytes.fromhex(_WATER12_HEX)
+    assert X.encode_frame(7, 0.014, box, _water12()) == want
+    w = traj.XtcWriter(os.devnull, 12)
+    got = w.encode(7, 0.014, np.array(box).reshape(3, 3), np.array(_water12(), dtype=np.float32))
+    w.close()
+    assert got == want
+    # run structure: every triple is one large atom plus a run of two small ones (the first two interchanged)
+    assert len(want) == 92 + 44
+
+
+def test_xtc_encoder_matches_independent_restatement():
+    import xtc3_reference as X
+    from mdx.io import traj
+    rng = np.random.default_rng(3)
+    box = [5.0, 0, 0, 0, 5.0, 0, 2.5, 2.5, 3.5]
+    for n in (10, 11, 30, 100, 999):
+        for spread in (0.02, 0.3, 5.0, 400.0):
+            x = (rng.normal(0, spread, size=(n, 3)) + rng.uniform(0, 5, size=3)).astype(np.float32)
+            want = X.encode_frame(3, 0.5, box, [tuple(float(c) for c in p) for p in x])
+            w = traj.XtcWriter(os.devnull, n)
+            got = w.encode(3, 0.5, np.array(box).reshape(3, 3), x)
+            w.close()
+            assert got == want, (n, spread)
+
+
+def test_xtc_threaded_encoder_gives_the_same_bytes():
+    """Frames encoded in speculative segments on several threads are byte-identical to the one-thread encoding, also
+    when the speculation fails (warm-up walk of zero atoms: the segments start from a wrong guess and are redone)."""
+    import mdx  # noqa: F401
+    from mdx import synth
+    from mdx.io import traj
+    L = traj.load_library()
+    rng = np.random.default_rng(5)
+    wat = synth.water_box(d=5.0).x
+    frames = {"water": wat,
+              "gas": rng.uniform(0, 30, size=(20000, 3)),
+              "mixed": np.concatenate([wat[:6000], rng.uniform(0, 30, size=(6000, 3)), wat[6000:15000]]),
+              "tight": rng.normal(0, 0.003, size=(12000, 3)) + 5}
+    box = np.diag([30.0, 30.0, 30.0])
+    for name, x in frames.items():
+        x = x.astype(np.float32)
+        one = traj.XtcWriter(os.devnull, len(x), threads=1).encode(0, 0.0, box, x)
+        for t in (2, 3, 4, 7, 16):
+            assert traj.XtcWriter(os.devnull, len(x), threads=t).encode(0, 0.0, box, x) == one, (name, t)
+        before = L.trj_xtc_respeculated()
+        old = L.trj_xtc_set_warmup(0)
+        try:
+            redo = traj.XtcWriter(os.devnull, len(x), threads=4).encode(0, 0.0, box, x)
+        finally:
+            L.trj_xtc_set_warmup(old)
+        assert redo == one, name
+        if name in ("water", "mixed"):
+            assert L.trj_xtc_respeculated() > before, name       # the fallback path did run
+    # and the frame still decodes to the rounded coordinates
+    p = os.path.join(os.environ.get("TMPDIR", "/tmp"), "mdx_mt_%d.xtc" % os.getpid())
+    w = traj.XtcWriter(p, len(wat), threads=4)
+    w.write(1, 0.002, box, wat.astype(np.float32)); w.close()
+    fr = traj.read_xtc(p); os.remove(p)
+    assert np.abs(fr[0]["x"] - wat).max() <= 0.501e-3
