@@ -160,7 +160,8 @@ def main():
     ap.add_argument("--no-output", action="store_true", help="diagnostic: skip the trajectory output the .mdp asks for")
     ap.add_argument("--chunk", type=int, default=0, help="diagnostic with --no-output: steps per mdx_step call")
     ap.add_argument("--ring", type=int, default=8, help="pinned trajectory-frame slots between the GPU and the encoder threads")
-    ap.add_argument("--encoders", type=int, default=3, help="host threads compressing trajectory frames")
+    ap.add_argument("--encoders", type=int, default=2, help="frames compressed at the same time (host threads)")
+    ap.add_argument("--encoder-threads", type=int, default=4, help="threads that share the compression of one frame (segments)")
     ap.add_argument("--prime-steps", type=int, default=40,
                     help="un-timed steps before the warmup that run every kernel variant, one pair search, the coupling steps and the "
                          "frame pipeline once (first launches and first frames carry one-off costs of milliseconds)")
@@ -207,7 +208,7 @@ def main():
         from mdx.io import traj
         from mdx.output import FramePipeline
         xtc_path = os.path.join(tempfile.gettempdir(), "mdx_bench_rank%d_%d.xtc" % (rank, os.getpid()))
-        xtc = traj.XtcWriter(xtc_path, s.natoms, precision=1000.0)
+        xtc = traj.XtcWriter(xtc_path, s.natoms, precision=1000.0, threads=args.encoder_threads)
         e.frame_ring(args.ring)
         pipe = FramePipeline(e, args.ring, xtc, None, None, dt, 0.0, nthreads=args.encoders)
 
@@ -311,7 +312,7 @@ def main():
                        ("pseudo-complex S2 (%d atoms), pull_short.mdp settings, constant-force COM pull, one replica per GPU, "
                         "xtc every 500 steps" % s.natoms),
                        "output": {"xtc_every": nst_xtc, "xtc_frames": xtc_frames, "xtc_MB": round(xtc_bytes / 1e6, 2),
-                                  "encoder_threads": args.encoders if nst_xtc else 0},
+                                  "frames_in_flight": args.encoders if nst_xtc else 0, "threads_per_frame": args.encoder_threads if nst_xtc else 0},
                        "natoms": s.natoms, "dt_ps": dt, "rc_nm": e.rc, "rlist_nm": round(e.rlist, 4), "nstlist": args.nstlist,
                        "pme_grid": list(e.grid), "parallelism": "replicas x%d" % world},
             "pair_interactions_per_s": round(n_rc / nb_avg_s, 1) if nb_avg_s > 0 else None,

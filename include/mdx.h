@@ -222,7 +222,9 @@ int mdx_synchronize(mdx_system *sys);
 /* Pair-list statistics (8 values): of the last search [0] super-clusters, [1] j-cluster
  * entries, [2] work units, [3] exclusion masks, [4] cluster pairs (set bits of the i-masks);
  * of the last energy step [5] non-excluded atom pairs with r < rc (each once), [6] those of
- * them with a Lennard-Jones term; [7] reserved. */
+ * them with a Lennard-Jones term; [7] streams the handle uses at present (3, or 1 after it found the GPU shared
+ * with another process: cross-stream waits are then served at the scheduler's time slice; MDX_STREAMS=1|3 in the
+ * environment pins the mode). */
 int mdx_get_list_stats(mdx_system *sys, long long *stats8);
 /* Energy frames recorded every nstcalcenergy steps since the last call: each frame is
  * (step, time, MDX_E_N terms). Returns the number of frames copied (<= max_frames). */
@@ -258,21 +260,6 @@ int mdx_dd_state_pointers(mdx_system *sys, void **x4_dev, void **v4_dev);
  * force-only launch (a stride such as 7 does not lock onto the 10- and 20-step cadences of energy and search steps). */
 int mdx_enable_kernel_timing(mdx_system *sys, int on);
 int mdx_get_kernel_timing(mdx_system *sys, double *nb_ms_total, long long *nb_launches);
-/* Diagnostics (no counterpart in the reference): time `iters` back-to-back launches of the
- * nonbonded kernel on the current pair list; select a kernel variant (key 1: 1 or 2). */
-int mdx_debug_time_nonbonded(mdx_system *sys, int energy, int iters, double *avg_ms);
-int mdx_debug_set(mdx_system *sys, int key, int value);
-/* One launch of the force-only nonbonded kernel with per-wave clocks: 10 values per wave (shader clock
- * at start and end, 100 MHz wall clock at start and end, work units, list entries, HW_ID, XCC_ID,
- * 8x8 tiles tested, tiles evaluated). */
-/* Diagnostic build (-DMDX_STAMPS) only: reset, or read, the per-kernel first-start / last-end time stamps. */
-int mdx_debug_stamps(mdx_system *sys, int reset, long long *out48);
-int mdx_debug_wave_times(mdx_system *sys, long long *out, int max_waves, int *nwaves);
-/* Average time (ms) of `iters` back-to-back runs of one stage on its own stream: 1 pair search,
- * 2 PME chain, 3 bonded + exclusion kernels, 4 update + constraints, 5 prepare, 6 PME spread, 7 PME gather.
- * The state is not meaningful afterwards (diagnostic only). */
-int mdx_debug_time_stage(mdx_system *sys, int stage, int iters, double *avg_ms);
-
 #ifdef __cplusplus
 }
 #endif

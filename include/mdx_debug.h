@@ -1,0 +1,35 @@
+/*
+ * mdx_debug.h — diagnostic entry points of libmdx.so: kernel timing experiments, launch-shape switches and per-kernel
+ * time stamps used by the tools under tools/ and by bench.py's roofline figures. None of them has a counterpart in
+ * the reference pipeline and none is needed to run a stage; they are kept apart from the run-time ABI of mdx.h.
+ */
+#ifndef MDX_DEBUG_H
+#define MDX_DEBUG_H
+#include "mdx.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Average time (ms) of `iters` back-to-back launches of the nonbonded kernel on the current pair list. */
+int mdx_debug_time_nonbonded(mdx_system *sys, int energy, int iters, double *avg_ms);
+/* Switches: key 1 nonbonded launch shape (10 * waves/SIMD of the energy kernel + waves/SIMD of the force kernel),
+ * 2 ablation bits of the timing experiments, 3 rounds of work units handed out dynamically (0: static deal),
+ * 4 log2 of the parts a dynamically handed unit is cut into, 5 early release of the side streams, 6 bonded kernels
+ * on the main stream, 7 charge spreading on the main stream, 8 PME gather on the main stream, 9 update behind the
+ * PME chain, 10 stream mode (0 automatic, 1 one stream, 3 three streams). */
+int mdx_debug_set(mdx_system *sys, int key, int value);
+/* Diagnostic build (-DMDX_STAMPS) only: reset, or read, the per-kernel first-start / last-end time stamps. */
+int mdx_debug_stamps(mdx_system *sys, int reset, long long *out48);
+/* One launch of the force-only nonbonded kernel with per-wave clocks: 10 values per wave (shader clock
+ * at start and end, 100 MHz wall clock at start and end, work units, list entries, HW_ID, XCC_ID,
+ * 8x8 tiles tested, tiles evaluated). */
+int mdx_debug_wave_times(mdx_system *sys, long long *out, int max_waves, int *nwaves);
+/* Average time (ms) of `iters` back-to-back runs of one stage on its own stream: 1 pair search,
+ * 2 PME chain, 3 bonded + exclusion kernels, 4 update + constraints, 5 prepare, 6 PME spread, 7 PME gather.
+ * The state is not meaningful afterwards (diagnostic only). */
+int mdx_debug_time_stage(mdx_system *sys, int stage, int iters, double *avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -4,7 +4,8 @@ The pipeline invokes `gmx <tool>` as child processes (/root/reference/Snakefile:
 /root/reference/scripts/run_smd_with_distance_monitoring.py:66-95). Putting `bin/gmx` of this
 repository first on PATH replaces the two MD tools and leaves the Snakefile and scripts
 unchanged; the preparation and analysis tools (`pdb2gmx`, `editconf`, `solvate`, `genion`,
-`trjconv`, `rms`, `make_ndx`) go to an installed GROMACS when there is one.
+`trjconv`, `rms`, `make_ndx`) go to an installed GROMACS when there is one; `trjconv -s P.tpr -f P.cpt -o P.gro`,
+the recovery step of the SMD drivers, is served from the shim's own run input and checkpoint.
 """
 from __future__ import annotations
 
@@ -33,6 +34,8 @@ def main(argv=None) -> int:
     if tool == "make_ndx" and (runner.find_real_gmx() is None or any(
             os.path.isfile(x + ".mdx") for x in rest if not x.startswith("-"))):
         return runner.make_ndx(rest)
+    if tool == "trjconv" and runner.trjconv_can_serve(rest):
+        return runner.trjconv(rest)
     real = runner.find_real_gmx()
     if real is None:
         sys.stderr.write(f"gmx {tool}: this tool is not part of the MD engine and no GROMACS installation was found "

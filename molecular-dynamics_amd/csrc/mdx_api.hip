@@ -93,6 +93,13 @@ extern "C" mdx_system *mdx_create(int device, int natoms)
               hipEventCreateWithFlags(&s->ev_bond, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_spread, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_nbdone, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
+    s->own_streams[0] = s->stream; s->own_streams[1] = s->st_pme; s->own_streams[2] = s->st_bond;
+    ok = ok && hipEventCreate(&s->ev_probe_a) == hipSuccess && hipEventCreate(&s->ev_probe_b) == hipSuccess;
+    // MDX_STREAMS=1 | 3 pins the stream mode (default: automatic, see stream_probe)
+    if (const char *e = getenv("MDX_STREAMS")) {
+        const int v = atoi(e);
+        if (v == 1 || v == 3) { s->stream_policy = v; if (v == 1 && ok) (void)mdx_set_stream_mode(s, 1); }
+    }
     const int n = natoms;
     // MDX_NB_DYN=0 in the environment selects the static deal of the nonbonded kernel (processes sharing one GPU)
     if (const char *e = getenv("MDX_NB_DYN")) s->nb_dyn = atoi(e);
@@ -154,10 +161,26 @@ extern "C" void mdx_destroy(mdx_system *s)
     if (s->ev_bond) (void)hipEventDestroy(s->ev_bond);
     if (s->ev_spread) (void)hipEventDestroy(s->ev_spread);
     if (s->ev_nbdone) (void)hipEventDestroy(s->ev_nbdone);
-    if (s->st_pme) (void)hipStreamDestroy(s->st_pme);
-    if (s->st_bond) (void)hipStreamDestroy(s->st_bond);
-    if (s->stream) (void)hipStreamDestroy(s->stream);
+    if (s->ev_probe_a) (void)hipEventDestroy(s->ev_probe_a);
+    if (s->ev_probe_b) (void)hipEventDestroy(s->ev_probe_b);
+    for (hipStream_t st : s->own_streams) if (st) (void)hipStreamDestroy(st);
     delete s;
+}
+
+// One stream per handle instead of three: the PME chain and the bonded kernels follow the nonbonded kernel in the
+// main stream's order, so no kernel of the handle ever waits for an event of another stream. Costs the overlap of
+// those chains (about a tenth of a step on an otherwise idle GPU); meant for several handles driven from threads of
+// one process and for processes that share a GPU, where more streams than hardware queues interleave in the queues.
+int mdx_set_stream_mode(mdx_system *s, int one_stream)
+{
+    (void)hipSetDevice(s->device);
+    MDX_CHECK(s, hipDeviceSynchronize());
+    s->one_stream = one_stream != 0;
+    s->stream = s->own_streams[0];
+    s->st_pme = s->one_stream ? s->own_streams[0] : s->own_streams[1];
+    s->st_bond = s->one_stream ? s->own_streams[0] : s->own_streams[2];
+    s->pme_signalled = false; s->gather_pending = nullptr;
+    return MDX_OK;
 }
 
 // ---------------------------------------------------------------- topology
@@ -766,7 +789,7 @@ extern "C" int mdx_get_list_stats(mdx_system *s, long long *st)
     int rc = sync_and_check(s); if (rc) return rc;
     st[0] = s->h->nsc; st[1] = s->h->ncj; st[2] = s->h->nwork; st[3] = s->h->nexcl;
     st[4] = (long long)s->h->ntiles;
-    st[5] = (long long)s->h->npairs_rc; st[6] = (long long)s->h->npairs_lj; st[7] = 0;
+    st[5] = (long long)s->h->npairs_rc; st[6] = (long long)s->h->npairs_lj; st[7] = s->one_stream ? 1 : 3;
     return MDX_OK;
 }
 
@@ -811,6 +834,37 @@ extern "C" int mdx_get_kernel_timing(mdx_system *s, double *ms, long long *launc
     return MDX_OK;
 }
 
+// Processes that share a GPU: a stream that waits for an event of another stream of the same process is then woken
+// at the granularity of the hardware scheduler's time slices (milliseconds) instead of microseconds, and a step with
+// its four cross-stream waits takes tens of milliseconds (measured: two 24 k-atom runs on one MI355X, 59 ms per step
+// with three streams per handle, 0.2 ms with one). The probe measures exactly that latency now and then: an event on
+// the main stream, a wait for it on the bonded stream (idle at that point), an event behind the wait. Two slow
+// probes in a row switch the handle to one stream; in one-stream mode the same probe runs on the then unused third
+// stream and three fast ones in a row switch back. No host synchronisation except at a switch.
+static int stream_probe(mdx_system *s)
+{
+    if (s->stream_policy != 0 || s->dd_on) return MDX_OK;
+    if (s->probe_pending) {
+        if (hipEventQuery(s->ev_probe_b) != hipSuccess) return MDX_OK;       // not there yet (or still slow): look again next step
+        float ms = 0.0f;
+        s->probe_pending = false;
+        if (hipEventElapsedTime(&ms, s->ev_probe_a, s->ev_probe_b) != hipSuccess) return MDX_OK;
+        s->probe_last_ms = ms;
+        if (ms > 0.5f) { s->probe_slow++; s->probe_fast = 0; } else if (ms < 0.1f) { s->probe_fast++; s->probe_slow = 0; } else { s->probe_slow = 0; s->probe_fast = 0; }
+        if (!s->one_stream && s->probe_slow >= 2) { s->mode_switches++; s->probe_slow = 0; return mdx_set_stream_mode(s, 1); }
+        if (s->one_stream && s->probe_fast >= 3) { s->mode_switches++; s->probe_fast = 0; return mdx_set_stream_mode(s, 0); }
+        // a first slow probe is confirmed at once, everything else waits for the regular cadence
+        s->probe_next_step = s->step + ((!s->one_stream && s->probe_slow > 0) ? 1 : 100);
+        return MDX_OK;
+    }
+    if (s->step < s->probe_next_step) return MDX_OK;
+    MDX_CHECK(s, hipEventRecord(s->ev_probe_a, s->stream));
+    MDX_CHECK(s, hipStreamWaitEvent(s->own_streams[2], s->ev_probe_a, 0));
+    MDX_CHECK(s, hipEventRecord(s->ev_probe_b, s->own_streams[2]));
+    s->probe_pending = true;
+    return MDX_OK;
+}
+
 // One MD step, or (domain decomposition) its two halves: phase 1 enqueues everything up to the charge
 // spreading and the short-range kernels and records ev_spread behind the spreading; the caller then sums the
 // charge grids of all domains; phase 2 enqueues the rest of the PME chain, the join, the update and the
@@ -841,6 +895,7 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early)
         // the side streams start when the prepare kernel completes (its completion signal is the fork event:
         // an event recorded by a separate marker costs the main stream several microseconds)
         if ((rc = mdx_launch_prepare(s, !forked_early))) return rc;
+        if (phase == 0) if ((rc = stream_probe(s))) return rc;
         // the nonbonded kernel is the critical path: enqueue it first, the side streams fill in
         const bool spread_main = s->spread_on_main != 0 && phase == 0;
         if (spread_main) if ((rc = mdx_launch_pme_spread(s, s->stream, true))) return rc;

@@ -170,15 +170,18 @@ class Transport:
 class ThreadTransport:
     """The same collectives between `world` domains that live in one process, one thread each (rehearsal and tests
     on a single GPU: processes that share a GPU are time-sliced far more coarsely than a step lasts, threads of one
-    process are not). Only one of the threads runs at any time: each holds the hub's lock while it computes and hands
-    it over while it waits for the others at a collective, so the handles never talk to the GPU runtime concurrently
-    (streams of several handles share a few hardware queues, and concurrent host threads inside the runtime were seen
-    to block each other for good). `Hub.run(fn)` starts `fn(rank, transport)` on `world` threads under that rule."""
+    process are not). The threads run concurrently and meet at the collectives. Their handles run in one-stream mode
+    (`mdx_debug_set` key 10): with three streams per handle, `world` handles put more streams into the process than it
+    has hardware queues, and kernels of one handle then queue behind event waits of another; with `exclusive=True`
+    only one thread runs at a time instead (each holds the hub's lock while it computes and hands it over at a
+    collective), which keeps three streams per handle. `Hub.run(fn)` starts `fn(rank, transport)` on `world`
+    threads."""
 
     class Hub:
-        def __init__(self, world: int):
+        def __init__(self, world: int, exclusive: bool = False):
             import threading
             self.world = world
+            self.exclusive = exclusive
             self.barrier = threading.Barrier(world)
             self.lock = threading.Lock()
             self.slots = [None] * world
@@ -188,11 +191,12 @@ class ThreadTransport:
 
         def run(self, fn):
             """fn(rank, transport) on one thread per domain; returns the list of results, re-raises the first error."""
+            import contextlib
             import threading
             res, err = [None] * self.world, []
 
             def body(rank):
-                with self.lock:
+                with (self.lock if self.exclusive else contextlib.nullcontext()):
                     try:
                         res[rank] = fn(rank, self.port(rank))
                     except BaseException as e:          # a failing domain must not leave the others at a barrier
@@ -209,17 +213,24 @@ class ThreadTransport:
 
     def __init__(self, hub, rank: int):
         self.hub, self.rank, self.world, self.staged, self.group = hub, rank, hub.world, False, None
-        self.serial = True          # DecomposedWater drains its handle before it hands the GPU over
+        self.in_process = True
+        self.serial = hub.exclusive     # DecomposedWater drains its handle before it hands the GPU over
+        self.stream = None              # torch stream of this thread's collectives (set by DecomposedWater)
 
     def _meet(self):
-        """All work of this thread complete, then wait for the others with the lock handed over."""
+        """All work of this thread complete, then wait for the others (with the lock handed over, if there is one)."""
         if torch.cuda.is_available():
-            torch.cuda.synchronize()
-        self.hub.lock.release()
+            if self.stream is not None and not self.hub.exclusive:
+                self.stream.synchronize()
+            else:
+                torch.cuda.synchronize()
+        if self.hub.exclusive:
+            self.hub.lock.release()
         try:
             self.hub.barrier.wait()
         finally:
-            self.hub.lock.acquire()
+            if self.hub.exclusive:
+                self.hub.lock.acquire()
 
     def all_gather(self, t):
         self.hub.slots[self.rank] = t
@@ -313,6 +324,8 @@ class DecomposedWater:
             # several ranks time-share one GPU (tests): the nonbonded kernel's ticket queues crawl under process
             # switching, the static deal does not
             self.engine.debug_set(3, 0)
+        if getattr(self.tr, "in_process", False) and not getattr(self.tr, "serial", False):
+            self.engine.debug_set(10, 1)        # several handles in one process: one stream each
         gp, gn = self.engine.dd_grid()
         self.grid_t = torch.as_tensor(_DevArray(gp, (gn,)), device=self.dev)
         # initial home set from the given coordinates

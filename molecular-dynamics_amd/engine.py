@@ -487,7 +487,7 @@ class Engine:
         st = (ctypes.c_longlong * 8)()
         self._call("mdx_get_list_stats", st)
         return dict(superclusters=st[0], cj_entries=st[1], work_units=st[2], excl_masks=st[3], cluster_pairs=st[4],
-                    pairs_within_rc=st[5], pairs_with_lj=st[6])
+                    pairs_within_rc=st[5], pairs_with_lj=st[6], streams=st[7])
 
     def pop_energy_frames(self, max_frames=8192):
         buf = np.zeros((max_frames, 2 + E_N), np.float64)

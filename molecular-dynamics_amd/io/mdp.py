@@ -30,6 +30,11 @@ DEFAULTS = {
     "define": "", "include": "", "title": "", "ns_type": "grid",
     "pull": "no", "pull_ncoords": "1", "pull_ngroups": "0", "pull_nstxout": "50", "pull_nstfout": "50",
     "pull_print_components": "no",
+    # energy minimisation (/root/reference/mdp/em.mdp:3-5, em_complex.mdp:3-5) and further documented keys that the
+    # engine reads or that only shape GROMACS-side behaviour the engine has no counterpart for
+    "emtol": "10.0", "emstep": "0.01", "nstcgsteep": "1000", "nbfgscorr": "10",
+    "epsilon_r": "1", "epsilon_rf": "0", "rvdw_switch": "0", "rcoulomb_switch": "0", "ewald_geometry": "3d",
+    "fourier_nx": "0", "fourier_ny": "0", "fourier_nz": "0", "lincs_warnangle": "30", "shake_tol": "0.0001",
 }
 _PULL_GROUP = re.compile(r"pull_group(\d+)_(name|pbcatom)$")
 _PULL_COORD = re.compile(r"pull_coord(\d+)_(type|geometry|groups|dim|start|k|rate|init|vec|origin)$")

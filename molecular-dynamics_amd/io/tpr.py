@@ -97,7 +97,8 @@ def save_checkpoint(path: str, step: int, time: float, x, v, box, extra: dict | 
 def load_checkpoint(path: str):
     """-> dict(step, time, x, v, box, extra)."""
     if not is_run_input(path):
-        raise ValueError(f"{path} is not a checkpoint written by this mdrun")
+        raise ValueError(f"{path} is not a checkpoint written by this mdrun (a GROMACS .cpt cannot be read: continue from the "
+                         "shim's own PREFIX.cpt, or start the stage from the .gro alone)")
     with np.load(path, allow_pickle=False) as z:
         header = json.loads(bytes(z["header"]).decode())
         if header.get("magic") != MAGIC_CPT:

@@ -308,6 +308,66 @@ def make_ndx(argv, stdin=None, out=sys.stdout, err=sys.stderr) -> int:
 
 
 # ------------------------------------------------------------------------------------------
+# trjconv: the one form the pipeline needs from the shim's own containers
+# ------------------------------------------------------------------------------------------
+def trjconv_can_serve(argv) -> bool:
+    """True for `gmx trjconv -s P.tpr -f P.cpt -o P.gro [-dump t]` on files this shim wrote: the recovery step of
+    the SMD drivers (/root/reference/scripts/run_smd_with_distance_monitoring.py:231-244,
+    /root/reference/scripts/run_smd_with_recovery.py:107-127). Everything else belongs to a real GROMACS."""
+    try:
+        a, _ = _trjconv_parser().parse_known_args(argv)
+    except SystemExit:
+        return False
+    if not (a.s and a.f and a.o) or not a.f.endswith(".cpt") or not a.o.endswith(".gro"):
+        return False
+    src = a.s + ".mdx" if os.path.isfile(a.s + ".mdx") else a.s
+    return tprio.is_run_input(src) and tprio.is_run_input(a.f)
+
+
+def _trjconv_parser():
+    p = argparse.ArgumentParser(prog="gmx trjconv", add_help=False, allow_abbrev=False)
+    p.add_argument("-s", default=None)
+    p.add_argument("-f", default=None)
+    p.add_argument("-o", default=None)
+    p.add_argument("-n", default=None)
+    p.add_argument("-dump", type=float, default=None)
+    return p
+
+
+def trjconv(argv, stdin=None, out=sys.stdout, err=sys.stderr) -> int:
+    """Writes the checkpoint's state as a `.gro` (the whole system, velocities included). The group number the
+    drivers pipe in (`0` = System) is read and must select the whole system; `-dump` is accepted for any value: a
+    checkpoint holds exactly one frame."""
+    a, _ = _trjconv_parser().parse_known_args(argv)
+    try:
+        src = a.s + ".mdx" if os.path.isfile(a.s + ".mdx") else a.s
+        sysm, _mdp, _meta = tprio.load_run_input(src)
+        cp = tprio.load_checkpoint(a.f)
+        if len(cp["x"]) != sysm.natoms:
+            raise InputError(f"checkpoint {a.f} has {len(cp['x'])} atoms, the run input {sysm.natoms}")
+        text = ""
+        if stdin is not None or not sys.stdin.isatty():
+            text = (stdin if stdin is not None else sys.stdin).read()
+        sel = text.split()[0] if text.split() else "0"
+        groups = sysm.groups
+        names = list(groups.names) if hasattr(groups, "names") else list(groups.keys())
+        if sel.lstrip("-").isdigit():
+            name = names[int(sel)] if 0 <= int(sel) < len(names) else None
+        else:
+            name = sel if sel in names else None
+        if name is None or len(groups[name]) != sysm.natoms:
+            raise InputError(f"trjconv: output group '{sel}' is not the whole system; only System (0) is served by the shim")
+        out.write(f"Select group for output\nSelected {sel}: '{name}'\n")
+        groio.write_system_gro(a.o, sysm, x=cp["x"], v=cp["v"], box=cp["box"],
+                               title=f"{sysm.title}, t= {cp['time']:.5f} step= {cp['step']}")
+        out.write(f"Dumping frame at t= {cp['time']:g} ps ({PROGRAM}: state of {a.f})\n")
+        return 0
+    except (InputError, ValueError, KeyError, IndexError, OSError) as e:
+        err.write(f"\nProgram:     gmx trjconv ({PROGRAM})\n\nFatal error:\n{e}\n")
+        return 1
+
+
+# ------------------------------------------------------------------------------------------
 # mdrun
 # ------------------------------------------------------------------------------------------
 def _mdrun_parser():
@@ -548,7 +608,7 @@ def mdrun(argv, out=sys.stdout, err=sys.stderr) -> int:
             if not appending:
                 _backup(f_xtc)
             xtc = traj.XtcWriter(f_xtc, sysm.natoms if sel is None else len(sel), precision=m.f("compressed_x_precision"),
-                                 append=appending)
+                                 append=appending, threads=4)
         if nst_x > 0 or nst_v > 0:
             from .io import traj
             if not appending:

@@ -16,7 +16,7 @@ import numpy as np
 def decomposed(world, nst, rest, d):
     import mdx
     from mdx import synth, domdec
-    hub = domdec.ThreadTransport.Hub(world)
+    hub = domdec.ThreadTransport.Hub(world, exclusive=bool(os.environ.get("MDX_DD_EXCLUSIVE")))
 
     def rank_main(rank, transport):
         s = synth.water_box(d=d)

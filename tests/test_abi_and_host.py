@@ -14,9 +14,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "mdx.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(mdx_[a-z0-9_]+)\s*\(", txt)))
+    names = set()
+    inc = os.path.join(ROOT, "include")
+    for h in sorted(os.listdir(inc)):
+        if h.endswith(".h"):
+            txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(inc, h)).read(), flags=re.S)
+            names |= set(re.findall(r"\b(mdx_[a-z0-9_]+)\s*\(", txt))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():

@@ -514,3 +514,67 @@ def test_xtc_threaded_encoder_gives_the_same_bytes():
     w.write(1, 0.002, box, wat.astype(np.float32)); w.close()
     fr = traj.read_xtc(p); os.remove(p)
     assert np.abs(fr[0]["x"] - wat).max() <= 0.501e-3
+
+
+# ------------------------------------------------------------------ the pipeline's own .mdp files, verbatim
+_REF_MDP = "/root/reference/mdp"
+
+
+@pytest.mark.skipif(not os.path.isdir(_REF_MDP), reason="reference tree not present on this machine")
+def test_reference_mdp_files_parse_with_the_expected_warnings():
+    """Every stage file of the pipeline read as it stands (/root/reference/mdp/*.mdp): the only key the reader does
+    not know is `nstcheckpoint` (pull_short.mdp:10, not an mdp key in GROMACS either, hence `-maxwarn 1000`); the
+    values the engine consumes come out as the files say."""
+    expect_unknown = {"pull_short.mdp": ["nstcheckpoint"]}
+    seen = {}
+    for name in sorted(os.listdir(_REF_MDP)):
+        if not name.endswith(".mdp"):
+            continue
+        m = mdp.read_mdp(os.path.join(_REF_MDP, name))
+        unknown = [w.split("'")[1] for w in m.warnings if "unknown left-hand" in w]
+        other = [w for w in m.warnings if "unknown left-hand" not in w]
+        assert unknown == expect_unknown.get(name, []), (name, m.warnings)
+        assert other == [], (name, other)
+        seen[name] = m
+    assert {"em.mdp", "em_complex.mdp", "nvt_complex.mdp", "npt_complex.mdp", "production.mdp", "pull_short.mdp"} <= set(seen)
+    em = seen["em_complex.mdp"]
+    assert em.s("integrator") == "steep" and em.f("emtol") == 1000.0 and em.f("emstep") == 0.01 and em.defines() == {"POSRES": ""}
+    pr = seen["production.mdp"]
+    assert pr.s("pcoupl") == "Parrinello-Rahman" and pr.f("tau_p") == 2.0 and pr.i("nstxout_compressed") == 10 and pr.i("nstenergy") == 10
+    assert pr.words("tc_grps") == ["Protein", "Non-Protein"] and pr.floats("tau_t") == [0.1, 0.1] and pr.s("dispcorr") == "EnerPres"
+    npt = seen["npt_complex.mdp"]
+    assert npt.i("nstpcouple") == 100 and npt.i("nsttcouple") == 100 and npt.s("refcoord_scaling") == "all" and npt.i("nstcomm") == 1000
+    pull = seen["pull_short.mdp"]
+    assert pull.s("pull_coord1_type") == "constant-force" and pull.f("pull_coord1_k") == 500.0 and pull.f("rcoulomb") == 1.2
+    assert pull.words("tc_grps") == ["Protein", "MOL", "SOL", "NA"] and pull.i("lincs_order") == 6 and pull.f("dt") == 0.001
+    nvt = seen["nvt_complex.mdp"]
+    assert nvt.b("gen_vel") and nvt.i("gen_seed") == -1 and not nvt.b("continuation")
+
+
+def test_trjconv_dumps_the_checkpoint_state(tmp_path):
+    """`gmx trjconv -s P.tpr -f P.cpt -o P.gro -dump 0` fed `0` as the SMD drivers do
+    (/root/reference/scripts/run_smd_with_distance_monitoring.py:231-244): served from the shim's own containers."""
+    from mdx import cli
+    s = synth.water_box(d=2.4)
+    d = str(tmp_path)
+    from mdx.io import ndx as ndxio
+    s.groups = ndxio.default_groups(s.resname, s.atomname) if s.resname is not None else s.groups
+    tpr.save_run_input(os.path.join(d, "smd.tpr"), s, {"integrator": "md"}, {})
+    rng = np.random.default_rng(1)
+    x = s.x + rng.normal(scale=0.01, size=s.x.shape); v = rng.normal(size=s.x.shape)
+    tpr.save_checkpoint(os.path.join(d, "smd.cpt"), 1234, 1.234, x, v, s.box)
+    argv = ["trjconv", "-s", os.path.join(d, "smd.tpr"), "-f", os.path.join(d, "smd.cpt"), "-o", os.path.join(d, "smd.gro"), "-dump", "0"]
+    assert runner.trjconv_can_serve(argv[1:])
+    out, err = io.StringIO(), io.StringIO()
+    assert runner.trjconv(argv[1:], stdin=io.StringIO("0\n"), out=out, err=err) == 0, err.getvalue()
+    g = gro.read_gro(os.path.join(d, "smd.gro"))
+    assert g.natoms == s.natoms and np.abs(g.x - x).max() < 5.1e-4 and np.abs(g.v - v).max() < 5.1e-5
+    assert "step= 1234" in g.title
+    # a group that is not the whole system is refused; other uses of trjconv are not the shim's
+    assert runner.trjconv(argv[1:], stdin=io.StringIO("SOL_missing\n"), out=io.StringIO(), err=io.StringIO()) == 1
+    assert not runner.trjconv_can_serve(["-s", os.path.join(d, "smd.tpr"), "-f", os.path.join(d, "traj.xtc"), "-o", os.path.join(d, "o.pdb")])
+    # a file that is not one of the shim's checkpoints gives a message, not a numpy error
+    with open(os.path.join(d, "real.cpt"), "wb") as f:
+        f.write(b"\x00\x00\x00\x10GROMACS checkpoint")
+    with pytest.raises(ValueError, match="GROMACS .cpt cannot be read"):
+        tpr.load_checkpoint(os.path.join(d, "real.cpt"))

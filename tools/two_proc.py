@@ -18,4 +18,4 @@ n = int(os.environ.get("NSTEPS", "300"))
 t0 = time.time()
 for k in range(n // 10):
     e.step(10); e.synchronize(); print("rank %d: %d steps %.2f s" % (rank, 10 * (k + 1), time.time() - t0), flush=True)
-print("rank %d: 300 steps in %.2f s" % (rank, time.time() - t0), flush=True)
+print("rank %d: %d steps in %.2f s, streams now %d" % (rank, n, time.time() - t0, e.list_stats()["streams"]), flush=True)
