@@ -1,0 +1,40 @@
+"""Two `mdrun`-like processes on one GPU, as Snakemake starts them when several poses run at once
+(/root/reference/Snakefile:520-802 fans the per-pose chains out over the `{pose}` wildcard): both have to make
+progress at normal speed. With three streams per handle each cross-stream wait of a step is served at the hardware
+scheduler's time slice once a second process is active (tens of milliseconds to seconds per step); the handles find
+each other through the per-GPU registry and run on one stream while they share the device."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_two_processes_share_one_gpu_at_normal_speed(tmp_path):
+    helper = os.path.join(ROOT, "tests", "shared_gpu_ranks.py")
+    env = dict(os.environ, LIMIT="100")
+    env.pop("MDX_STREAMS", None)
+    procs = [subprocess.Popen([sys.executable, helper, str(r), str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in (0, 1)]
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=150)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("a process sharing the GPU did not finish")
+        assert p.returncode == 0, o[-1000:] + e[-3000:]
+        outs.append(json.loads([l for l in o.splitlines() if l.startswith("{")][-1]))
+    res, new = outs
+    # the newcomer found the resident and ran on one stream from its first step
+    assert set(new["modes"]) == {1}, new["modes"]
+    # the resident started on three streams, shared on one, and went back to three once alone
+    m = res["modes"]
+    assert m[0] == 3 and 1 in m and m[-1] == 3, m
+    # nobody crawled: a 10-step chunk of this 17 k-atom box takes a few milliseconds; the pathological case is >0.5 s
+    assert new["worst_chunk_s"] < 0.25 and res["worst_chunk_s"] < 0.25, (res["worst_chunk_s"], new["worst_chunk_s"])
