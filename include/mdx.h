@@ -222,9 +222,7 @@ int mdx_synchronize(mdx_system *sys);
 /* Pair-list statistics (8 values): of the last search [0] super-clusters, [1] j-cluster
  * entries, [2] work units, [3] exclusion masks, [4] cluster pairs (set bits of the i-masks);
  * of the last energy step [5] non-excluded atom pairs with r < rc (each once), [6] those of
- * them with a Lennard-Jones term; [7] streams the handle uses at present (3, or 1 after it found the GPU shared
- * with another process: cross-stream waits are then served at the scheduler's time slice; MDX_STREAMS=1|3 in the
- * environment pins the mode). */
+ * them with a Lennard-Jones term; [7] streams the handle uses (3; 1 in the diagnostic one-stream mode). */
 int mdx_get_list_stats(mdx_system *sys, long long *stats8);
 /* Energy frames recorded every nstcalcenergy steps since the last call: each frame is
  * (step, time, MDX_E_N terms). Returns the number of frames copied (<= max_frames). */

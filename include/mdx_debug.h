@@ -16,7 +16,7 @@ int mdx_debug_time_nonbonded(mdx_system *sys, int energy, int iters, double *avg
  * 2 ablation bits of the timing experiments, 3 rounds of work units handed out dynamically (0: static deal),
  * 4 log2 of the parts a dynamically handed unit is cut into, 5 early release of the side streams, 6 bonded kernels
  * on the main stream, 7 charge spreading on the main stream, 8 PME gather on the main stream, 9 update behind the
- * PME chain, 10 stream mode (0 automatic, 1 one stream, 3 three streams). */
+ * PME chain, 10 streams per handle (1 or 3). */
 int mdx_debug_set(mdx_system *sys, int key, int value);
 /* Diagnostic build (-DMDX_STAMPS) only: reset, or read, the per-kernel first-start / last-end time stamps. */
 int mdx_debug_stamps(mdx_system *sys, int reset, long long *out48);

@@ -5,12 +5,6 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
-#include <dirent.h>
-#include <signal.h>
-#include <unistd.h>
-#include <sys/stat.h>
-#include <errno.h>
-#include <mutex>
 
 static thread_local std::string g_create_err;
 
@@ -57,9 +51,6 @@ static void scratch_lookup(int device)
     g_scratch_ptr[device] = (e == hipSuccess) ? p : nullptr;
 }
 
-static void registry_enter(int device);
-static void registry_leave(int device);
-static int registry_count(int device, int *others_on_three);
 
 extern "C" int mdx_version(void) { return 100; }
 
@@ -89,40 +80,23 @@ extern "C" mdx_system *mdx_create(int device, int natoms)
     if (device < 0 || device >= ndev) { g_create_err = "device index out of range"; return nullptr; }
     if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return nullptr; }
     scratch_lookup(device);
-    registry_enter(device);
     mdx_system *s = new mdx_system();
     s->device = device; s->n = natoms;
-    // the side streams get the highest priority so that their small kernels take wave slots as soon
-    // as the wide nonbonded grid on the main stream frees any
-    int prio_least = 0, prio_greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    bool ok = hipStreamCreate(&s->stream) == hipSuccess &&
-              hipStreamCreateWithPriority(&s->st_pme, hipStreamDefault, prio_greatest) == hipSuccess &&
-              hipStreamCreateWithPriority(&s->st_bond, hipStreamDefault, prio_greatest) == hipSuccess &&
+    // All three streams at the default priority. High-priority side streams bring nothing on a GPU of one's own (694
+    // against 687 ns/day on the bench workload) and are ruinous on a shared one: hardware queues of a higher priority
+    // pre-empt the running waves of every other queue, so two processes, or several handles in one process, keep
+    // evicting each other's pair kernel (measured on MI355X: two 24 k-atom runs sharing the device take 59 ms to
+    // seconds per step with high-priority side streams, 0.3 ms at equal priorities).
+    bool ok = hipStreamCreate(&s->stream) == hipSuccess && hipStreamCreate(&s->st_pme) == hipSuccess &&
+              hipStreamCreate(&s->st_bond) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_pme, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_bond, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_spread, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_nbdone, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
     s->own_streams[0] = s->stream; s->own_streams[1] = s->st_pme; s->own_streams[2] = s->st_bond;
-    ok = ok && hipEventCreate(&s->ev_probe_a) == hipSuccess && hipEventCreate(&s->ev_probe_b) == hipSuccess;
-    // MDX_STREAMS=1 | 3 pins the stream mode (default: automatic, see stream_probe)
-    if (const char *e = getenv("MDX_STREAMS")) {
-        const int v = atoi(e);
-        if (v == 1 || v == 3) { s->stream_policy = v; if (v == 1 && ok) (void)mdx_set_stream_mode(s, 1); }
-    }
-    if (ok) (void)mdx_registry_poll(s);
-    if (ok && s->stream_policy == 0 && s->one_stream) {
-        // Another engine process already runs on this GPU. It switches to one stream at its next pair search or
-        // mdx_step call; starting kernels before it has would make its steps already enqueued crawl, so wait for
-        // its entry to say so (a process that is not stepping does not answer: give up after three seconds).
-        for (int tries = 0; tries < 1500; tries++) {
-            int on_three = 0;
-            (void)registry_count(device, &on_three);
-            if (on_three == 0) break;
-            usleep(2000);
-        }
-    }
+    // MDX_STREAMS=1: every kernel of the handle on one stream (diagnostic; three streams are the default)
+    if (const char *e = getenv("MDX_STREAMS")) if (atoi(e) == 1 && ok) (void)mdx_set_stream_mode(s, 1);
     const int n = natoms;
     // MDX_NB_DYN=0 in the environment selects the static deal of the nonbonded kernel (processes sharing one GPU)
     if (const char *e = getenv("MDX_NB_DYN")) s->nb_dyn = atoi(e);
@@ -184,123 +158,13 @@ extern "C" void mdx_destroy(mdx_system *s)
     if (s->ev_bond) (void)hipEventDestroy(s->ev_bond);
     if (s->ev_spread) (void)hipEventDestroy(s->ev_spread);
     if (s->ev_nbdone) (void)hipEventDestroy(s->ev_nbdone);
-    if (s->ev_probe_a) (void)hipEventDestroy(s->ev_probe_a);
-    if (s->ev_probe_b) (void)hipEventDestroy(s->ev_probe_b);
     for (hipStream_t st : s->own_streams) if (st) (void)hipStreamDestroy(st);
-    registry_leave(s->device);
     delete s;
 }
 
-// ---------------------------------------------------------------- processes sharing a GPU
-// Every process that creates a handle on a GPU leaves a file named after its pid in a directory named after the
-// GPU's PCI bus id (under /dev/shm, else /tmp). A handle in automatic stream mode counts the live entries when it is
-// created and at every fourth pair search: more than one process means one stream per handle (see stream_probe for
-// why), a process alone goes back to three. Entries of processes that no longer exist are removed by whoever sees
-// them. Processes that do not share the directory (other containers) are left to the latency probe.
-static std::mutex g_reg_mutex;
-static int g_reg_refs[MDX_MAX_DEVICES] = { 0 };
-static std::string g_reg_dir[MDX_MAX_DEVICES];
-
-static std::string registry_dir(int device)
-{
-    char bus[64] = { 0 };
-    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) snprintf(bus, sizeof(bus), "dev%d", device);
-    for (char *c = bus; *c; c++) if (*c == ':' || *c == '/') *c = '_';
-    const char *roots[] = { "/dev/shm", "/tmp" };
-    for (const char *r : roots) {
-        const std::string d = std::string(r) + "/mdx-gpu-" + bus;
-        if (mkdir(d.c_str(), 0777) == 0 || errno == EEXIST) { (void)chmod(d.c_str(), 0777); return d; }
-    }
-    return std::string();
-}
-
-static void registry_enter(int device)
-{
-    if (device < 0 || device >= MDX_MAX_DEVICES) return;
-    std::lock_guard<std::mutex> lk(g_reg_mutex);
-    if (g_reg_refs[device]++ > 0) return;
-    g_reg_dir[device] = registry_dir(device);
-    if (g_reg_dir[device].empty()) return;
-    const std::string f = g_reg_dir[device] + "/" + std::to_string((long long)getpid());
-    FILE *fp = fopen(f.c_str(), "w");
-    if (fp) fclose(fp);
-}
-
-static void registry_leave(int device)
-{
-    if (device < 0 || device >= MDX_MAX_DEVICES) return;
-    std::lock_guard<std::mutex> lk(g_reg_mutex);
-    if (--g_reg_refs[device] > 0 || g_reg_dir[device].empty()) return;
-    (void)unlink((g_reg_dir[device] + "/" + std::to_string((long long)getpid())).c_str());
-}
-
-// this process's entry carries '1' once its handles run on one stream, '3' before
-static void registry_publish(int device, bool one_stream)
-{
-    if (device < 0 || device >= MDX_MAX_DEVICES) return;
-    std::string dir;
-    { std::lock_guard<std::mutex> lk(g_reg_mutex); dir = g_reg_dir[device]; }
-    if (dir.empty()) return;
-    FILE *fp = fopen((dir + "/" + std::to_string((long long)getpid())).c_str(), "w");
-    if (fp) { fputc(one_stream ? '1' : '3', fp); fclose(fp); }
-}
-
-// live processes registered on the device (this one included); 1 when there is no registry.
-// *others_on_three: how many of the others have not switched to one stream yet.
-static int registry_count(int device, int *others_on_three)
-{
-    if (others_on_three) *others_on_three = 0;
-    if (device < 0 || device >= MDX_MAX_DEVICES) return 1;
-    std::string dir;
-    { std::lock_guard<std::mutex> lk(g_reg_mutex); dir = g_reg_dir[device]; }
-    if (dir.empty()) return 1;
-    DIR *d = opendir(dir.c_str());
-    if (!d) return 1;
-    int n = 0;
-    const long long me = (long long)getpid();
-    while (struct dirent *e = readdir(d)) {
-        char *end = nullptr;
-        const long long pid = strtoll(e->d_name, &end, 10);
-        if (end == e->d_name || *end != 0 || pid <= 0) continue;
-        if (pid == me) { n++; continue; }
-        if (kill((pid_t)pid, 0) == 0 || errno == EPERM) {
-            n++;
-            if (others_on_three) {
-                char c = '3';
-                FILE *fp = fopen((dir + "/" + e->d_name).c_str(), "r");
-                if (fp) { const int g = fgetc(fp); if (g != EOF) c = (char)g; fclose(fp); }
-                if (c != '1') (*others_on_three)++;
-            }
-        } else (void)unlink((dir + "/" + e->d_name).c_str());
-    }
-    closedir(d);
-    return n > 0 ? n : 1;
-}
-
-// Follow the registry (automatic stream mode only): called when a handle is created and now and then from the pair search.
-int mdx_registry_poll(mdx_system *s)
-{
-    if (s->stream_policy != 0) return MDX_OK;
-    const bool shared = registry_count(s->device, nullptr) > 1;
-    if (shared && !s->one_stream) {
-        s->shared_by_registry = true; s->mode_switches++;
-        const int rc = mdx_set_stream_mode(s, 1);
-        registry_publish(s->device, true);
-        return rc;
-    }
-    if (shared && s->one_stream) registry_publish(s->device, true);
-    if (!shared && s->one_stream && s->shared_by_registry) {
-        s->shared_by_registry = false; s->mode_switches++; s->probe_fast = 0;
-        registry_publish(s->device, false);
-        return mdx_set_stream_mode(s, 0);
-    }
-    return MDX_OK;
-}
-
-// One stream per handle instead of three: the PME chain and the bonded kernels follow the nonbonded kernel in the
-// main stream's order, so no kernel of the handle ever waits for an event of another stream. Costs the overlap of
-// those chains (about a tenth of a step on an otherwise idle GPU); meant for several handles driven from threads of
-// one process and for processes that share a GPU, where more streams than hardware queues interleave in the queues.
+// One stream per handle instead of three (diagnostic, mdx_debug_set key 10 / MDX_STREAMS=1): the PME chain and the
+// bonded kernels follow the nonbonded kernel in the main stream's order, so no kernel of the handle ever waits for an
+// event of another stream. Costs the overlap of those chains (489 against 703 ns/day on the bench workload).
 int mdx_set_stream_mode(mdx_system *s, int one_stream)
 {
     (void)hipSetDevice(s->device);
@@ -964,38 +828,6 @@ extern "C" int mdx_get_kernel_timing(mdx_system *s, double *ms, long long *launc
     return MDX_OK;
 }
 
-// Processes that share a GPU: a stream that waits for an event of another stream of the same process is then woken
-// at the granularity of the hardware scheduler's time slices (milliseconds) instead of microseconds, and a step with
-// its four cross-stream waits takes tens of milliseconds (measured: two 24 k-atom runs on one MI355X, 59 ms per step
-// with three streams per handle, 0.2 ms with one). The probe measures exactly that latency now and then: an event on
-// the main stream, a wait for it on the bonded stream (idle at that point), an event behind the wait. Two slow
-// probes in a row switch the handle to one stream; in one-stream mode the same probe runs on the then unused third
-// stream and three fast ones in a row switch back. No host synchronisation except at a switch.
-static int stream_probe(mdx_system *s)
-{
-    if (s->stream_policy != 0 || s->dd_on) return MDX_OK;
-    if (s->probe_pending) {
-        if (hipEventQuery(s->ev_probe_b) != hipSuccess) return MDX_OK;       // not there yet (or still slow): look again next step
-        float ms = 0.0f;
-        s->probe_pending = false;
-        if (hipEventElapsedTime(&ms, s->ev_probe_a, s->ev_probe_b) != hipSuccess) return MDX_OK;
-        s->probe_last_ms = ms;
-        if (ms > 0.5f) { s->probe_slow++; s->probe_fast = 0; } else if (ms < 0.1f) { s->probe_fast++; s->probe_slow = 0; } else { s->probe_slow = 0; s->probe_fast = 0; }
-        // (a latency of several milliseconds is decisive on its own; a moderately slow probe has to repeat)
-        if (!s->one_stream && (s->probe_slow >= 2 || ms > 5.0f)) { s->mode_switches++; s->probe_slow = 0; return mdx_set_stream_mode(s, 1); }
-        if (s->one_stream && s->probe_fast >= 3) { s->mode_switches++; s->probe_fast = 0; return mdx_set_stream_mode(s, 0); }
-        // a first slow probe is confirmed at once, everything else waits for the regular cadence
-        s->probe_next_step = s->step + ((!s->one_stream && s->probe_slow > 0) ? 1 : 100);
-        return MDX_OK;
-    }
-    if (s->step < s->probe_next_step) return MDX_OK;
-    MDX_CHECK(s, hipEventRecord(s->ev_probe_a, s->stream));
-    MDX_CHECK(s, hipStreamWaitEvent(s->own_streams[2], s->ev_probe_a, 0));
-    MDX_CHECK(s, hipEventRecord(s->ev_probe_b, s->own_streams[2]));
-    s->probe_pending = true;
-    return MDX_OK;
-}
-
 // One MD step, or (domain decomposition) its two halves: phase 1 enqueues everything up to the charge
 // spreading and the short-range kernels and records ev_spread behind the spreading; the caller then sums the
 // charge grids of all domains; phase 2 enqueues the rest of the PME chain, the join, the update and the
@@ -1026,7 +858,6 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early)
         // the side streams start when the prepare kernel completes (its completion signal is the fork event:
         // an event recorded by a separate marker costs the main stream several microseconds)
         if ((rc = mdx_launch_prepare(s, !forked_early))) return rc;
-        if (phase == 0) if ((rc = stream_probe(s))) return rc;
         // the nonbonded kernel is the critical path: enqueue it first, the side streams fill in
         const bool spread_main = s->spread_on_main != 0 && phase == 0;
         if (spread_main) if ((rc = mdx_launch_pme_spread(s, s->stream, true))) return rc;
@@ -1109,7 +940,6 @@ extern "C" int mdx_step(mdx_system *s, long long nsteps)
         MDX_CHECK(s, hipStreamSynchronize(s->stream));
         s->pull_reset_pending = false;
     }
-    if ((rc = mdx_registry_poll(s))) return rc;
     bool forked_early = false;
     for (long long it = 0; it < nsteps; it++)
         if ((rc = step_phase(s, 0, it + 1 < nsteps, forked_early))) return rc;

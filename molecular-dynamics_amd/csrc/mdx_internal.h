@@ -121,12 +121,6 @@ struct mdx_system {
     long long *nb_wave_t = nullptr;    // diagnostic per-wave clock buffer (mdx_debug_wave_times)
     int nb_variant = 33;               // nonbonded launch shape: 10 * waves/SIMD of the energy kernel + waves/SIMD of the force kernel
     bool one_stream = false;           // st_pme and st_bond are the main stream (no cross-stream waits at all)
-    // Stream mode: 0 automatic (three streams unless the probe below finds cross-stream waits slow), 1 or 3 pinned.
-    int stream_policy = 0;
-    hipEvent_t ev_probe_a = nullptr, ev_probe_b = nullptr;   // timing events of the cross-stream wake-up probe
-    bool probe_pending = false; long long probe_next_step = 0; int probe_slow = 0, probe_fast = 0;
-    float probe_last_ms = 0.0f; long long mode_switches = 0;
-    int searches_since_registry_check = 0; bool shared_by_registry = false;
     hipStream_t own_streams[3] = { nullptr, nullptr, nullptr };   // the three streams created for the handle (destroyed with it)
     hipStream_t stream = nullptr;      // main stream: search, nonbonded, update
     hipStream_t st_pme = nullptr;      // PME chain (spread, FFTs, solve, gather) overlaps the nonbonded kernel
@@ -258,7 +252,6 @@ struct mdx_system {
 
 // kernels' host launchers (each returns MDX_OK or an error code)
 int mdx_set_stream_mode(mdx_system *s, int one_stream);
-int mdx_registry_poll(mdx_system *s);
 int mdx_search(mdx_system *s);
 int mdx_fork(mdx_system *s);
 int mdx_join(mdx_system *s);

@@ -570,10 +570,9 @@ extern "C" int mdx_debug_set(mdx_system *s, int key, int value)
     if (key == 6) { s->bond_on_main = value; return MDX_OK; }
     if (key == 5) { s->early_fork = value; return MDX_OK; }
     if (key == 4 && value >= 0 && value <= 3) { s->nb_dyn_split = value; return MDX_OK; }
-    if (key == 10) {      // stream mode: 0 automatic, 1 one stream (pinned), 3 three streams (pinned)
-        if (value != 0 && value != 1 && value != 3) { s->err = "mdx_debug_set: key 10 takes 0, 1 or 3"; return MDX_ERR_ARG; }
-        s->stream_policy = value;
-        return value == 0 ? MDX_OK : mdx_set_stream_mode(s, value == 1);
+    if (key == 10) {      // streams per handle: 1 (every kernel in one stream's order) or 3
+        if (value != 1 && value != 3) { s->err = "mdx_debug_set: key 10 takes 1 or 3"; return MDX_ERR_ARG; }
+        return mdx_set_stream_mode(s, value == 1);
     }
     s->err = "mdx_debug_set: unknown key"; return MDX_ERR_ARG;
 }

@@ -644,12 +644,6 @@ static void build_shift_list(mdx_system *s, const double *box)
 
 int mdx_search(mdx_system *s)
 {
-    // other engine processes on this GPU? (a directory listing)
-    if (++s->searches_since_registry_check >= 1) {
-        s->searches_since_registry_check = 0;
-        const int rcp = mdx_registry_poll(s);
-        if (rcp) return rcp;
-    }
     // host copy of the box (may lag the device by a few coupling steps; only used for grid counts)
     const double *box = s->h->boxd;
     build_shift_list(s, box);

@@ -169,13 +169,9 @@ class Transport:
 
 class ThreadTransport:
     """The same collectives between `world` domains that live in one process, one thread each (rehearsal and tests
-    on a single GPU: processes that share a GPU are time-sliced far more coarsely than a step lasts, threads of one
-    process are not). The threads run concurrently and meet at the collectives. Their handles run in one-stream mode
-    (`mdx_debug_set` key 10): with three streams per handle, `world` handles put more streams into the process than it
-    has hardware queues, and kernels of one handle then queue behind event waits of another; with `exclusive=True`
-    only one thread runs at a time instead (each holds the hub's lock while it computes and hands it over at a
-    collective), which keeps three streams per handle. `Hub.run(fn)` starts `fn(rank, transport)` on `world`
-    threads."""
+    on a single GPU). The threads run concurrently, each driving its own handle, and meet at the collectives; with
+    `exclusive=True` only one thread runs at a time (each holds the hub's lock while it computes and hands it over at
+    a collective). `Hub.run(fn)` starts `fn(rank, transport)` on `world` threads."""
 
     class Hub:
         def __init__(self, world: int, exclusive: bool = False):
@@ -320,12 +316,6 @@ class DecomposedWater:
         self.engine = eng.Engine(tmpl, rc=rc, rlist=self.rlist, dt=dt, nstlist=nstlist, pme=True, grid=grid, device=device,
                                  tc_groups=["System"] if ref_t is not None else None, ref_t=[ref_t or 300.0], tau_t=[tau_t],
                                  nsttcouple=nsttcouple, nstcalcenergy=nstcalcenergy, nstcomm=0, seed=seed + self.rank)
-        if shared_device:
-            # several ranks time-share one GPU (tests): the nonbonded kernel's ticket queues crawl under process
-            # switching, the static deal does not
-            self.engine.debug_set(3, 0)
-        if getattr(self.tr, "in_process", False) and not getattr(self.tr, "serial", False):
-            self.engine.debug_set(10, 1)        # several handles in one process: one stream each
         gp, gn = self.engine.dd_grid()
         self.grid_t = torch.as_tensor(_DevArray(gp, (gn,)), device=self.dev)
         # initial home set from the given coordinates

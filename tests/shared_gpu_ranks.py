@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Helper of test_gpu_shared.py: one of two engine processes on the same GPU. The resident (role 0) starts alone on
-three streams and keeps stepping; the newcomer (role 1) starts once the resident has run for a while, runs its own
+"""Helper of test_gpu_shared.py: one of two engine processes on the same GPU. The resident (role 0) starts alone
+and keeps stepping; the newcomer (role 1) starts once the resident has run for a while, runs its own
 steps and leaves; the resident then carries on alone. Each prints one JSON line: wall time of every 10-step chunk
 and the stream mode the handle reported after each chunk.
 python tests/shared_gpu_ranks.py ROLE FLAGDIR"""

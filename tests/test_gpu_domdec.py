@@ -20,7 +20,7 @@ def _run(world, box):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,box", [(2, 9.0)])     # 4 domains pass too (two minutes on one GPU: 12 streams share 4 hardware queues)
+@pytest.mark.parametrize("world,box", [(2, 9.0), (4, 9.0)])
 def test_domains_match_single_handle(world, box):
     res = _run(world, box)
     part = res["traj"]["partition"]

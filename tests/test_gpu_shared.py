@@ -1,8 +1,8 @@
 """Two `mdrun`-like processes on one GPU, as Snakemake starts them when several poses run at once
 (/root/reference/Snakefile:520-802 fans the per-pose chains out over the `{pose}` wildcard): both have to make
-progress at normal speed. With three streams per handle each cross-stream wait of a step is served at the hardware
-scheduler's time slice once a second process is active (tens of milliseconds to seconds per step); the handles find
-each other through the per-GPU registry and run on one stream while they share the device."""
+progress at normal speed. (With side streams of a higher priority than the main stream, as an earlier version of the
+engine created them, the hardware queues of the two processes keep pre-empting each other's pair kernel and a step
+takes tens of milliseconds to seconds; all streams of a handle now have the default priority.)"""
 import json
 import os
 import subprocess
@@ -31,10 +31,8 @@ def test_two_processes_share_one_gpu_at_normal_speed(tmp_path):
         assert p.returncode == 0, o[-1000:] + e[-3000:]
         outs.append(json.loads([l for l in o.splitlines() if l.startswith("{")][-1]))
     res, new = outs
-    # the newcomer found the resident and ran on one stream from its first step
-    assert set(new["modes"]) == {1}, new["modes"]
-    # the resident started on three streams, shared on one, and went back to three once alone
-    m = res["modes"]
-    assert m[0] == 3 and 1 in m and m[-1] == 3, m
+    # both kept their three streams (the PME and bonded chains overlap the pair kernel as on a GPU of their own)
+    assert set(new["modes"]) == {3} and set(res["modes"]) == {3}
+    assert res["n_shared"] > 20 and new["chunks"] == 60
     # nobody crawled: a 10-step chunk of this 17 k-atom box takes a few milliseconds; the pathological case is >0.5 s
     assert new["worst_chunk_s"] < 0.25 and res["worst_chunk_s"] < 0.25, (res["worst_chunk_s"], new["worst_chunk_s"])
