@@ -295,6 +295,9 @@ def main():
         allw = ensemble.gather_work(rec[:, 3])
         dF = ensemble.jarzynski_free_energy(allw, 300.0)
         smd = dict(samples=int(len(rec)), replicas=int(allw.shape[0]), final_distance=float(rec[-1, 1]) if len(rec) else None,
+                   initial_distance=float(rec[0, 1]) if len(rec) else None, k=500.0,
+                   work_final_rank0=float(rec[-1, 3]) if len(rec) else None,
+                   work_final_all=[float(w) for w in allw[:, -1]] if len(rec) else None,
                    jarzynski_dF_final=float(dF[-1]) if len(dF) else None)
     elif use_dist:
         # replicas only: one tiny RCCL all-gather of the final potential energies (no data-path collective)

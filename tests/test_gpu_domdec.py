@@ -31,3 +31,39 @@ def test_domains_match_single_handle(world, box):
     assert res["rest"]["dv_rel_rms"] < 2e-5, res
     # 12 steps with one renewal of the partition: 2.3e-7 nm RMS, the same as the one-domain path against the plain handle
     assert res["traj"]["dx_rms"] < 2e-6 and res["traj"]["dx_max"] < 5e-5, res
+
+
+@pytest.mark.gpu
+def test_decomposed_path_at_the_tiled_million_atom_size():
+    """Config 5 at its size on one GPU: the tiled water box (2x2x2 copies of the 12.5 nm dodecahedron, 1.1 M atoms)
+    through the decomposed path with one rank against the plain single handle on the same state, plus the properties
+    a water box has to keep (rigid molecules, no net momentum gained)."""
+    import numpy as np
+    import mdx  # noqa: F401
+    from mdx import synth, engine as eng, domdec
+    base = synth.water_box(d=12.5)
+    big = synth.tiled(base, (2, 2, 2))
+    assert big.natoms > 1_000_000
+    nst = 12
+    dd = domdec.DecomposedWater(big, device=0, rc=1.0, dt=0.002, nstlist=10, ref_t=None, rlist=1.1)
+    assert dd.world == 1 and dd.n_halo == 0 and dd.n_home == big.natoms // 3
+    dd.step(nst); dd.synchronize()
+    x, v = dd.gather_state()
+    tiles = dd.engine.list_stats()["cluster_pairs"]
+    dd.close()
+    e = eng.Engine(big, rc=1.0, dt=0.002, nstlist=10, rlist=1.1, nstcalcenergy=0, nstcomm=0)
+    e.step(nst); e.synchronize()
+    xr, vr, _ = e.get_state()
+    tiles_ref = e.list_stats()["cluster_pairs"]
+    e.close()
+    dx = x - xr
+    dx -= np.round(dx @ np.linalg.inv(big.box)) @ big.box
+    assert np.sqrt((dx ** 2).mean()) < 2e-6 and np.abs(dx).max() < 1e-4
+    assert abs(tiles - tiles_ref) < 0.01 * tiles_ref
+    # rigid water geometry and momentum
+    x = x.astype(np.float64)
+    doh = np.linalg.norm(x[0::3] - x[1::3], axis=1); dhh = np.linalg.norm(x[1::3] - x[2::3], axis=1)
+    assert np.abs(doh / 0.09572 - 1).max() < 1e-4 and np.abs(dhh / 0.15139 - 1).max() < 1e-4
+    p0 = (big.mass[:, None] * big.v).sum(0); p1 = (big.mass[:, None] * v).sum(0)
+    prms = np.sqrt((big.mass[:, None] * v) ** 2).mean() * np.sqrt(big.natoms)
+    assert np.abs(p1 - p0).max() < 0.05 * prms            # the mesh part conserves momentum to PME accuracy only
