@@ -75,17 +75,24 @@ struct MdxStamp {
     long long *mx;
     // first workgroup stamps the start, the last one (by index: about the last to be dispatched) the end; plain
     // stores, because thousands of workgroups updating one address would themselves stretch the kernel
-    __device__ MdxStamp(const DevState *d, int id) {
+    // (all_end: every workgroup stamps the end with an atomic maximum, for a kernel whose last workgroups may be idle)
+    bool amax;
+    __device__ MdxStamp(const DevState *d, int id, bool all_end = false) {
         DevState *w = const_cast<DevState *>(d);
-        mx = nullptr;
+        mx = nullptr; amax = all_end;
         if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) w->ts_min[id] = (long long)wall_clock64();
-        if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1) mx = &w->ts_max[id];
+        if (threadIdx.x == 0 && (all_end || (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1))) mx = &w->ts_max[id];
     }
-    __device__ ~MdxStamp() { if (mx) *mx = (long long)wall_clock64(); }
+    __device__ ~MdxStamp() {
+        if (!mx) return;
+        if (amax) atomicMax((unsigned long long *)mx, (unsigned long long)wall_clock64()); else *mx = (long long)wall_clock64();
+    }
 };
 #define MDX_STAMP(d, id) MdxStamp stamp_((d), (id))
+#define MDX_STAMP_ALL(d, id) MdxStamp stamp_((d), (id), true)
 #else
 #define MDX_STAMP(d, id)
+#define MDX_STAMP_ALL(d, id)
 #endif
 __device__ __forceinline__ int mdx_rep() { return (int)((blockIdx.x + 5u * blockIdx.y) & (MDX_NREP - 1)); }
 #define MDX_ENER(dw, t) ((dw)->ener_rep[mdx_rep()][t])

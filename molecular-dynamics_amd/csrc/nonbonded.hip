@@ -401,6 +401,17 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __syncthreads();
     nb_body<false, false, 4 | 16>(A, (const float2 *)tab4, ilj);
 }
+// Four i-clusters at a time (two passes over the unit's entries) at four waves per SIMD: a quarter fewer registers per
+// wave, a third more waves to cover the LDS and memory latencies.
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_f4tl4(NbArgs A)
+{
+    __shared__ float4 tab4[MDX_GTAB_N / 2];
+    __shared__ float2 ilj[16 * 64];
+    const float4 *src = (const float4 *)A.gtab;
+    for (int k = threadIdx.x; k < MDX_GTAB_N / 2; k += 1024) tab4[k] = src[k];
+    __syncthreads();
+    nb_body<false, false, 4 | 16, 4>(A, (const float2 *)tab4, ilj);
+}
 // The same at 128 registers (a few spills): leaves half a SIMD's register file to co-running kernels.
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_f3t128(NbArgs A)
 {
@@ -491,7 +502,7 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
         else if (s->dbg & 0x200000) kern = k_nonbonded_f3_abl2;
         else if ((s->dbg & 0x400000) || !s->gtab) kern = k_nonbonded_f3;
         else { kern = (s->dbg & 0x800000) ? k_nonbonded_f3t128 : ((s->dbg & 0x4000000) ? k_nonbonded_f3t : k_nonbonded_f3tl); grid = dim3(256); block = dim3(768); }
-    }
+    } else if (wv == 4 && s->gtab && !(s->dbg & 0x400000)) { kern = k_nonbonded_f4tl4; grid = dim3(256); block = dim3(1024); }
     hipExtLaunchKernelGGL(kern, grid, block, 0, s->stream, ev_a, ev_b, 0, A);
     MDX_CHECK(s, hipGetLastError());
     return MDX_OK;

@@ -7,6 +7,8 @@
 #include <hip/hip_ext.h>
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
+#include <cmath>
 
 __device__ __forceinline__ void bspline4(float t, float *w, float *dw)
 {
@@ -143,6 +145,118 @@ __global__ __launch_bounds__(256) void k_pme_spread_col(SpreadArgs A, const DevS
         }
     }
     __syncthreads();
+    for (int k = threadIdx.x; k < nt; k += blockDim.x) {
+        const int vi = ((const int *)tile)[k];
+        if (vi == 0) continue;
+        const float v = (float)vi * (1.0f / MDX_SPREAD_SCALE);
+        const int rx = k % A.T0, ry = (k / A.T0) % A.T1, pl = k / (A.T0 * A.T1);
+        const int gz = pmod(tp0 + pl - 3, A.K2), gy = pmod(oy[pl] + ry, A.K1), gx = pmod(ox[pl] + rx, A.K0);
+        atomicAdd(&A.grid[((size_t)gz * A.K1 + gy) * A.K0 + gx], v);
+    }
+}
+
+// Charge spreading with one thread per atom. A workgroup takes up to four consecutive super-clusters of one
+// pair-search column (256 sorted slots: atoms that lie on top of each other in z) and accumulates them into an LDS
+// window of its own: the column's footprint in x and y, the planes those atoms can reach in z. Each thread evaluates
+// its atom's splines once and adds its 4 x 4 x 4 contributions with integer LDS atomics (fixed point, 2^-26 e); the
+// window's non-zero points are then added to the grid with float atomics. Against one workgroup per (column, slab of
+// planes) with four threads per atom this evaluates every atom once instead of twelve times (every slab's workgroup
+// walked the whole column), which is what counts beside the nonbonded kernel, where these waves get the issue slots
+// that kernel leaves over. Window origins are kept per plane as above (the cell's c vector is tilted).
+struct SpreadChunkArgs {
+    int ncx, ncy;
+    const int *col_scstart;
+    const float4 *x;
+    const int *perm, *perm_src, *shift_s;
+    const float4 *sbb_lo, *sbb_hi;      // super-cluster bounding boxes of the last search (brick coordinates)
+    int K0, K1, K2;
+    int T0, T1, PPC;                    // window size in x, y and planes
+    int sc_per_chunk;                   // super-clusters per workgroup (<= 4)
+    float delta;
+    float *grid;
+    const float4 *v_home;
+};
+
+__global__ __launch_bounds__(256) void k_pme_spread_chunk(SpreadChunkArgs A, const DevState *__restrict__ d)
+{
+    MDX_STAMP_ALL(d, 3);
+    extern __shared__ float tile[];
+    int *ox = (int *)(tile + A.PPC * A.T1 * A.T0);
+    int *oy = ox + A.PPC;
+    __shared__ int s_tp0;
+    const int col = blockIdx.x;
+    const int sc_first = A.col_scstart[col] + blockIdx.y * A.sc_per_chunk;
+    const int sc_end = min(A.col_scstart[col + 1], sc_first + A.sc_per_chunk);
+    if (sc_first >= sc_end) return;                 // uniform for the workgroup
+    const DevBox &bx = d->box;
+    const float wx = bx.h[0] / A.ncx, wy = bx.h[4] / A.ncy;
+    const int cxi = col % A.ncx, cyi = col / A.ncx;
+    const float x_lo = cxi * wx - A.delta, x_hi = (cxi + 1) * wx + A.delta;
+    const float y_lo = cyi * wy - A.delta, y_hi = (cyi + 1) * wy + A.delta;
+    // lowest plane the chunk's atoms can touch: floor(u_z) + 3 in tile-plane numbering (as in k_pme_spread_col)
+    const float zmin = A.sbb_lo[sc_first].z - A.delta;
+    const int tp0 = (int)floorf(A.K2 * bx.inv[8] * zmin) + 3;
+    for (int p = threadIdx.x; p < A.PPC; p += blockDim.x) {
+        const int tp = tp0 + p;
+        const float z_lo = (tp - 6) / (A.K2 * bx.inv[8]) - A.delta, z_hi = (tp - 2) / (A.K2 * bx.inv[8]) + A.delta;
+        const float ux = A.K0 * (x_lo * bx.inv[0] + fminf(y_lo * bx.inv[3], y_hi * bx.inv[3]) + fminf(z_lo * bx.inv[6], z_hi * bx.inv[6]));
+        const float uy = A.K1 * (y_lo * bx.inv[4] + fminf(z_lo * bx.inv[7], z_hi * bx.inv[7]));
+        ox[p] = (int)floorf(ux); oy[p] = (int)floorf(uy);
+    }
+    const int nt = A.PPC * A.T1 * A.T0;
+#pragma unroll 1
+    for (int k = threadIdx.x; k < nt; k += blockDim.x) tile[k] = 0.0f;
+    __syncthreads();
+    const int gs = sc_first * 64 + threadIdx.x;
+    if (gs < sc_end * 64 && A.perm[gs] >= 0) {
+        const int src = A.perm_src[gs];
+        float4 p = A.x[src];
+        const bool skip = p.w == 0.0f || (A.v_home && A.v_home[src].w == 0.0f);
+        if (!skip) {
+            int sa, sb, sc;
+            unpack_shift(A.shift_s[gs], sa, sb, sc);
+            p.x += sa * bx.h[0] + sb * bx.h[3] + sc * bx.h[6];
+            p.y += sb * bx.h[4] + sc * bx.h[7];
+            p.z += sc * bx.h[8];
+            float u[3];
+            grid_coords(bx, p, A.K0, A.K1, A.K2, u);
+            const int px = (int)floorf(u[0]), py = (int)floorf(u[1]), pz = (int)floorf(u[2]);
+            float wxs[4], wys[4], wzs[4], dws[4];
+            bspline4(u[0] - px, wxs, dws); bspline4(u[1] - py, wys, dws); bspline4(u[2] - pz, wzs, dws);
+            const float qs = p.w * MDX_SPREAD_SCALE;
+            // (at most 40 registers, so that three of these waves fit on a SIMD beside three 128-register nonbonded waves)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int pl = pz + c + 3 - tp0;
+                const float wzc = (c == 0) ? wzs[0] : ((c == 1) ? wzs[1] : ((c == 2) ? wzs[2] : wzs[3]));
+                const float qz = qs * wzc;
+                const bool inpl = pl >= 0 && pl < A.PPC;
+                const int rx0 = inpl ? px - ox[pl] : -1, ry0 = inpl ? py - oy[pl] : -1;
+                if (rx0 >= 0 && rx0 + 3 < A.T0 && ry0 >= 0 && ry0 + 3 < A.T1) {
+                    int *t = (int *)tile + (pl * A.T1 + ry0) * A.T0 + rx0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const float qzy = qz * wys[b];
+#pragma unroll
+                        for (int a = 0; a < 4; a++) atomicAdd(&t[b * A.T0 + a], __float2int_rn(qzy * wxs[a]));
+                    }
+                } else {
+                    // outside the window (an atom that drifted far, or a chunk taller than the window): straight to the grid
+                    const int gz = pmod(pz + c, A.K2);
+                    const float qzf = p.w * wzc;
+#pragma unroll 1
+                    for (int ba = 0; ba < 16; ba++) {       // rare path: rolled, registers matter more than speed here
+                        const int b = ba >> 2, a = ba & 3;
+                        const float wyb = (b == 0) ? wys[0] : ((b == 1) ? wys[1] : ((b == 2) ? wys[2] : wys[3]));
+                        const float wxa = (a == 0) ? wxs[0] : ((a == 1) ? wxs[1] : ((a == 2) ? wxs[2] : wxs[3]));
+                        atomicAdd(&A.grid[((size_t)gz * A.K1 + pmod(py + b, A.K1)) * A.K0 + pmod(px + a, A.K0)], qzf * wyb * wxa);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
     for (int k = threadIdx.x; k < nt; k += blockDim.x) {
         const int vi = ((const int *)tile)[k];
         if (vi == 0) continue;
@@ -648,8 +762,26 @@ int mdx_launch_pme_spread(mdx_system *s, hipStream_t st, bool signal)
         A.ppc = (planes + nchunk - 1) / nchunk;
         A.delta = (float)delta; A.grid = s->grid; A.v_home = s->dd_on ? s->v : nullptr;
         if (getenv("MDX_PME_NOTILE")) { A.T0 = 4; A.T1 = 4; }
+        static const bool use_col = getenv("MDX_SPREAD") && !strcmp(getenv("MDX_SPREAD"), "col");
+        if (!use_col) {
+            SpreadChunkArgs C;
+            C.ncx = s->ncx; C.ncy = s->ncy; C.col_scstart = s->col_scstart; C.x = s->x; C.perm = s->perm; C.perm_src = s->perm_src;
+            C.shift_s = s->shift_s; C.sbb_lo = s->sbb_lo; C.sbb_hi = s->sbb_hi; C.K0 = K0; C.K1 = K1; C.K2 = K2; C.T0 = A.T0; C.T1 = A.T1;
+            C.sc_per_chunk = 4;
+            // planes a chunk of four super-clusters reaches: their height (a super-cluster of 64 atoms is about as tall
+            // as a column is wide; taller ones in thin regions fall back to the grid) plus the spline support and the margin
+            const double sc_h = std::cbrt(64.0 * (bxd[0] * bxd[4] * bxd[8]) / std::max(1, s->n));
+            C.PPC = std::min(K2 + 8, (int)ceil((C.sc_per_chunk * sc_h * 1.15 + 2 * delta) * K2 * inv8) + 5);
+            while ((size_t)C.PPC * C.T0 * C.T1 * 4 > 60 * 1024 && C.PPC > 8) C.PPC--;
+            C.delta = (float)delta; C.grid = s->grid; C.v_home = s->dd_on ? s->v : nullptr;
+            const size_t ldsc = (size_t)C.PPC * C.T0 * C.T1 * 4 + (size_t)C.PPC * 8;
+            // columns hold at most MDX_MAX_COL atoms = 32 super-clusters
+            const int ychunks = (MDX_MAX_COL / 64 + C.sc_per_chunk - 1) / C.sc_per_chunk;
+            hipLaunchKernelGGL(k_pme_spread_chunk, dim3(s->ncx * s->ncy, ychunks), dim3(256), ldsc, st, C, (const DevState *)s->d);
+        } else {
         const size_t lds = (size_t)A.ppc * A.T0 * A.T1 * 4 + (size_t)A.ppc * 8;
         hipLaunchKernelGGL(k_pme_spread_col, dim3(s->ncx * s->ncy, nchunk), dim3(256), lds, st, A, (const DevState *)s->d);
+        }
         MDX_CHECK(s, hipGetLastError());
         if (signal) {
             // a marker behind the kernel (a completion signal on the kernel itself holds the next kernel of this queue back by ~19 us)
