@@ -178,7 +178,7 @@ struct mdx_system {
     // nonbonded parameters
     float rc = 1.0f, rlist = 1.1f, beta = 3.12341f;
     float4 *htab = nullptr;       // ... with h(w) = erf(z)/z beside g, for the energy kernel
-    float2 *gtab = nullptr;       // MDX_GTAB_N entries of the Ewald correction g on a uniform r^2 grid up to rc^2
+    float2 *gtab = nullptr;       // MDX_GTAB_N entries of beta^3 g (Ewald correction of the force) on a uniform r^2 grid up to rc^2
     int nstlist = 10;
     // PME
     int K[3] = {0, 0, 0};

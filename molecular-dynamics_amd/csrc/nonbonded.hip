@@ -33,7 +33,7 @@ struct NbArgs {
     int do_pairs, do_excl;       // evaluate listed pairs / the Ewald correction of excluded pairs
     int dbg;                     // diagnostic ablation bits (timing experiments only)
     const float4 *htab;          // MDX_GTAB_N entries (g, step of g, h, step of h), h(w) = erf(z)/z
-    const float2 *gtab;          // MDX_GTAB_N entries (g(w_k), g(w_k+1) - g(w_k)), w_k = beta^2 rc^2 k / MDX_GTAB_N
+    const float2 *gtab;          // MDX_GTAB_N entries beta^3 (g(w_k), g(w_k+1) - g(w_k)), w_k = beta^2 rc^2 k / MDX_GTAB_N
     float tab_scale;             // MDX_GTAB_N / rc^2
     int dyn_split;               // log2 of the parts a unit is cut into when handed out dynamically
     int dyn;                     // rounds' worth of units at the cheap end of the list handed out dynamically (0: static deal only)
@@ -155,14 +155,15 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
         float2 *myilj = ILDS ? ilj + (threadIdx.x >> 6) * 64 : nullptr;
         if (ILDS) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // the previous pass has read its values
         float fix[NI], fiy[NI], fiz[NI];
+        // (one load and one LDS store per wave: lane l brings the pair of the l-th i-atom)
+        if (ILDS && lane < NI * 8) myilj[lane] = A.lj_s[(sci * 8 + c0) * 8 + lane];
 #pragma unroll
         for (int c = 0; c < NI; c++) {
             const int ia = (sci * 8 + c0 + c) * 8 + ti;
             const float4 p = A.xq_s[ia];
-            const float2 l = A.lj_s[ia];
             xi[c] = p.x - S.x; yi[c] = p.y - S.y; zi[c] = p.z - S.z;
             qi[c] = p.w * MDX_ONE_4PI_EPS0;
-            if (ILDS) { if (tj == 0) myilj[c * 8 + ti] = l; } else { hsi[c] = l.x; sei[c] = l.y; }
+            if (!ILDS) { const float2 l = A.lj_s[ia]; hsi[c] = l.x; sei[c] = l.y; }
             fix[c] = 0.0f; fiy[c] = 0.0f; fiz[c] = 0.0f;
         }
         // (LDS operations of one wave execute in order; the fence only keeps the compiler from moving the reads of
@@ -176,6 +177,8 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
         unsigned ex_n = 0xFFu;
         if (mk_n >> 8) ex_n = A.exclmask[(size_t)(mk_n >> 8) * 64 + lane];
         float hold = 0.0f; int hold_addr = 0; bool hold_did = false;
+        float2 li_nx = make_float2(0.0f, 0.0f);
+        if (ILDS && (ABL & 32)) li_nx = myilj[ti];
         for (int e = 0; e < count; e++) {
             const int cj = cj_n;
             const float4 pj = pj_n;
@@ -205,6 +208,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                 exh = ex >> c0;
             }
             float fjx = 0.0f, fjy = 0.0f, fjz = 0.0f;
+            float2 li_pf = make_float2(0.0f, 0.0f);
             bool did = false;           // wave-uniform: some tile of this entry had a pair inside the cutoff
             // One 8x8 tile: i-cluster c against the j-cluster. GENERAL tiles look at the exclusion and
             // liveness bits; the others (no mask slot, not a cluster with itself: the large majority, and
@@ -226,7 +230,8 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                 const float rinv = __frsqrt_rn(r2);
                 const float rinv2 = rinv * rinv;
                 float hs_c, se_c;
-                if (ILDS) { const float2 li = myilj[c * 8 + ti]; hs_c = li.x; se_c = li.y; } else { hs_c = hsi[c]; se_c = sei[c]; }
+                if (ILDS && (ABL & 32) && !GENERAL) { hs_c = li_pf.x; se_c = li_pf.y; }
+                else if (ILDS) { const float2 li = myilj[c * 8 + ti]; hs_c = li.x; se_c = li.y; } else { hs_c = hsi[c]; se_c = sei[c]; }
                 const float sg = hs_c + lj.x;
                 const float e4 = se_c * lj.y;
                 const float s2 = sg * sg * rinv2;
@@ -270,9 +275,12 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                         // the look-up runs on the LDS pipe next to the LJ arithmetic and replaces a dozen VALU instructions
                         const float t = r2 * A.tab_scale;
                         const float2 te = gtab[(unsigned)t & (MDX_GTAB_N - 1)];
-                        g = fmaf(__builtin_amdgcn_fractf(t), te.y, te.x);
-                    } else g = (ABL & 1) ? beta2 * r2 : mdx_pmecorr(beta2 * r2);
-                    fs = fmaf(-qq * beta3, g, fs);
+                        g = fmaf(__builtin_amdgcn_fractf(t), te.y, te.x);      // the table holds beta^3 g
+                        fs = fmaf(-qq, g, fs);
+                    } else {
+                        g = (ABL & 1) ? beta2 * r2 : mdx_pmecorr(beta2 * r2);
+                        fs = fmaf(-qq * beta3, g, fs);
+                    }
                 }
                 fs = within ? fs : 0.0f;
                 const float fx = fs * dx, fy = fs * dy, fz = fs * dz;
@@ -297,7 +305,18 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                     vyy = fmaf(dy, fy, vyy); vyz = fmaf(dy, fz, vyz); vzz = fmaf(dz, fz, vzz);
                 }
             };
-            if (!general) {
+            if (!general && ILDS && (ABL & 32)) {
+                // the i-atoms' LJ pair of the next listed tile is requested before the current tile is evaluated
+#pragma unroll
+                for (int c = 0; c < NI; c++) {
+                    if (imask & (1u << c)) {
+                        li_pf = li_nx;
+                        if (c + 1 < NI) li_nx = myilj[(c + 1) * 8 + ti];
+                        tile(std::false_type{}, c);
+                    } else if (c + 1 < NI) li_nx = myilj[(c + 1) * 8 + ti];
+                }
+                li_nx = myilj[ti];
+            } else if (!general) {
 #pragma unroll
                 for (int c = 0; c < NI; c++)
                     if (imask & (1u << c)) tile(std::false_type{}, c);
@@ -306,6 +325,10 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                 for (int c = 0; c < NI; c++)
                     if (imask & (1u << c)) tile(std::true_type{}, c);
             }
+            // The wave waits for the next entry's j-atoms here, ahead of this entry's force atomics: memory operations
+            // retire in order, so a wait placed behind the atomics (where the values are first used) would also wait for
+            // the atomics to reach the L2, once per entry.
+            asm volatile("" :: "v"(pj_n.x), "v"(pj_n.y), "v"(pj_n.z), "v"(pj_n.w), "v"(lj_n.x), "v"(lj_n.y), "v"(ex_n));
             // an entry none of whose tiles had a pair inside the cutoff has no j-force to reduce or add
             if (did && !(ABL & 2)) { fjx = sum8(fjx); fjy = sum8(fjy); fjz = sum8(fjz); }
             const int ja3 = 3 * (cj * 8 + tj);
@@ -400,6 +423,16 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int k = threadIdx.x; k < MDX_GTAB_N / 2; k += 768) tab4[k] = src[k];
     __syncthreads();
     nb_body<false, false, 4 | 16>(A, (const float2 *)tab4, ilj);
+}
+// The same with the i-atoms' LJ pair of the next tile requested one tile ahead.
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3tlp(NbArgs A)
+{
+    __shared__ float4 tab4[MDX_GTAB_N / 2];
+    __shared__ float2 ilj[12 * 64];
+    const float4 *src = (const float4 *)A.gtab;
+    for (int k = threadIdx.x; k < MDX_GTAB_N / 2; k += 768) tab4[k] = src[k];
+    __syncthreads();
+    nb_body<false, false, 4 | 16 | 32>(A, (const float2 *)tab4, ilj);
 }
 // Four i-clusters at a time (two passes over the unit's entries) at four waves per SIMD: a quarter fewer registers per
 // wave, a third more waves to cover the LDS and memory latencies.
@@ -501,7 +534,7 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
         else if (s->dbg & 0x100000) kern = k_nonbonded_f3_abl1;
         else if (s->dbg & 0x200000) kern = k_nonbonded_f3_abl2;
         else if ((s->dbg & 0x400000) || !s->gtab) kern = k_nonbonded_f3;
-        else { kern = (s->dbg & 0x800000) ? k_nonbonded_f3t128 : ((s->dbg & 0x4000000) ? k_nonbonded_f3t : k_nonbonded_f3tl); grid = dim3(256); block = dim3(768); }
+        else { kern = (s->dbg & 0x800000) ? k_nonbonded_f3t128 : ((s->dbg & 0x4000000) ? k_nonbonded_f3t : ((s->dbg & 0x8000000) ? k_nonbonded_f3tlp : k_nonbonded_f3tl)); grid = dim3(256); block = dim3(768); }
     } else if (wv == 4 && s->gtab && !(s->dbg & 0x400000)) { kern = k_nonbonded_f4tl4; grid = dim3(256); block = dim3(1024); }
     hipExtLaunchKernelGGL(kern, grid, block, 0, s->stream, ev_a, ev_b, 0, A);
     MDX_CHECK(s, hipGetLastError());
