@@ -854,10 +854,7 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early)
             if ((rc = mdx_launch_tcouple(s))) return rc;
         }
         s->first_step = false;
-        if (need_vir) {
-            if ((rc = mdx_launch_clear(s, true, true, true))) return rc;
-            if ((rc = mdx_launch_ke(s, true, true))) return rc;
-        }
+        if (need_vir) if ((rc = mdx_launch_clear(s, true, true, true))) return rc;
         // the leap-frog kernel leaves f cleared; only a force evaluation outside the step loop dirties it
         if (s->f_dirty) { MDX_CHECK(s, hipMemsetAsync(s->f, 0, sizeof(float) * 3 * s->n, s->stream)); s->f_dirty = false; }
         if (do_search) if ((rc = mdx_search(s))) return rc;
@@ -876,6 +873,9 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early)
             MDX_CHECK(s, hipEventRecord(s->ev_spread, s->st_pme));
         }
         if ((rc = mdx_launch_bonded(s, need_vir, MDX_F_BONDED | MDX_F_POSRES))) return rc;
+        // kinetic energy of the half step behind: reads only the velocities, which the update (behind the join) changes,
+        // so it runs on the bonded stream beside the nonbonded kernel instead of ahead of it on the main stream
+        if (need_vir) if ((rc = mdx_launch_ke(s, true, true, s->st_bond))) return rc;
         if (s->pull_on) {
             const bool log_now = (step % s->pull_nstout == 0);
             if ((rc = mdx_launch_pull(s, log_now, need_vir))) return rc;

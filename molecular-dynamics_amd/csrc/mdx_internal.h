@@ -272,7 +272,7 @@ int mdx_launch_pull(mdx_system *s, bool log_now, bool energy);
 int mdx_launch_update(mdx_system *s, bool do_tc, bool do_pr, bool virial);
 int mdx_launch_constrain(mdx_system *s, float inv_dt, bool virial, int lincs_iter);
 void mdx_frames_free(mdx_system *s);
-int mdx_launch_ke(mdx_system *s, bool old_slot, bool tensor);
+int mdx_launch_ke(mdx_system *s, bool old_slot, bool tensor, hipStream_t st = nullptr);
 int mdx_launch_clear(mdx_system *s, bool energies, bool ekin_new, bool ekin_old);
 int mdx_launch_tcouple(mdx_system *s);
 int mdx_launch_pcouple(mdx_system *s);

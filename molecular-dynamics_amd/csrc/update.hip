@@ -539,10 +539,10 @@ int mdx_launch_constrain(mdx_system *s, float inv_dt, bool virial, int lincs_ite
     return MDX_OK;
 }
 
-int mdx_launch_ke(mdx_system *s, bool old_slot, bool tensor)
+int mdx_launch_ke(mdx_system *s, bool old_slot, bool tensor, hipStream_t st)
 {
     const int nb = std::min((s->n + 255) / 256, 128);
-    hipLaunchKernelGGL(k_ke, dim3(nb), dim3(256), 0, s->stream, s->n, s->v, s->tcgrp, s->ntc, s->d, old_slot ? 1 : 0, tensor ? 1 : 0);
+    hipLaunchKernelGGL(k_ke, dim3(nb), dim3(256), 0, st ? st : s->stream, s->n, s->v, s->tcgrp, s->ntc, s->d, old_slot ? 1 : 0, tensor ? 1 : 0);
     MDX_CHECK(s, hipGetLastError());
     return MDX_OK;
 }
