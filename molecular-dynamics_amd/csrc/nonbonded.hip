@@ -177,8 +177,6 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
         unsigned ex_n = 0xFFu;
         if (mk_n >> 8) ex_n = A.exclmask[(size_t)(mk_n >> 8) * 64 + lane];
         float hold = 0.0f; int hold_addr = 0; bool hold_did = false;
-        float2 li_nx = make_float2(0.0f, 0.0f);
-        if (ILDS && (ABL & 32)) li_nx = myilj[ti];
         for (int e = 0; e < count; e++) {
             const int cj = cj_n;
             const float4 pj = pj_n;
@@ -208,7 +206,6 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                 exh = ex >> c0;
             }
             float fjx = 0.0f, fjy = 0.0f, fjz = 0.0f;
-            float2 li_pf = make_float2(0.0f, 0.0f);
             bool did = false;           // wave-uniform: some tile of this entry had a pair inside the cutoff
             // One 8x8 tile: i-cluster c against the j-cluster. GENERAL tiles look at the exclusion and
             // liveness bits; the others (no mask slot, not a cluster with itself: the large majority, and
@@ -230,8 +227,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                 const float rinv = __frsqrt_rn(r2);
                 const float rinv2 = rinv * rinv;
                 float hs_c, se_c;
-                if (ILDS && (ABL & 32) && !GENERAL) { hs_c = li_pf.x; se_c = li_pf.y; }
-                else if (ILDS) { const float2 li = myilj[c * 8 + ti]; hs_c = li.x; se_c = li.y; } else { hs_c = hsi[c]; se_c = sei[c]; }
+                if (ILDS) { const float2 li = myilj[c * 8 + ti]; hs_c = li.x; se_c = li.y; } else { hs_c = hsi[c]; se_c = sei[c]; }
                 const float sg = hs_c + lj.x;
                 const float e4 = se_c * lj.y;
                 const float s2 = sg * sg * rinv2;
@@ -305,18 +301,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                     vyy = fmaf(dy, fy, vyy); vyz = fmaf(dy, fz, vyz); vzz = fmaf(dz, fz, vzz);
                 }
             };
-            if (!general && ILDS && (ABL & 32)) {
-                // the i-atoms' LJ pair of the next listed tile is requested before the current tile is evaluated
-#pragma unroll
-                for (int c = 0; c < NI; c++) {
-                    if (imask & (1u << c)) {
-                        li_pf = li_nx;
-                        if (c + 1 < NI) li_nx = myilj[(c + 1) * 8 + ti];
-                        tile(std::false_type{}, c);
-                    } else if (c + 1 < NI) li_nx = myilj[(c + 1) * 8 + ti];
-                }
-                li_nx = myilj[ti];
-            } else if (!general) {
+            if (!general) {
 #pragma unroll
                 for (int c = 0; c < NI; c++)
                     if (imask & (1u << c)) tile(std::false_type{}, c);
@@ -424,16 +409,6 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __syncthreads();
     nb_body<false, false, 4 | 16>(A, (const float2 *)tab4, ilj);
 }
-// The same with the i-atoms' LJ pair of the next tile requested one tile ahead.
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3tlp(NbArgs A)
-{
-    __shared__ float4 tab4[MDX_GTAB_N / 2];
-    __shared__ float2 ilj[12 * 64];
-    const float4 *src = (const float4 *)A.gtab;
-    for (int k = threadIdx.x; k < MDX_GTAB_N / 2; k += 768) tab4[k] = src[k];
-    __syncthreads();
-    nb_body<false, false, 4 | 16 | 32>(A, (const float2 *)tab4, ilj);
-}
 // Four i-clusters at a time (two passes over the unit's entries) at four waves per SIMD: a quarter fewer registers per
 // wave, a third more waves to cover the LDS and memory latencies.
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_f4tl4(NbArgs A)
@@ -534,7 +509,7 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
         else if (s->dbg & 0x100000) kern = k_nonbonded_f3_abl1;
         else if (s->dbg & 0x200000) kern = k_nonbonded_f3_abl2;
         else if ((s->dbg & 0x400000) || !s->gtab) kern = k_nonbonded_f3;
-        else { kern = (s->dbg & 0x800000) ? k_nonbonded_f3t128 : ((s->dbg & 0x4000000) ? k_nonbonded_f3t : ((s->dbg & 0x8000000) ? k_nonbonded_f3tlp : k_nonbonded_f3tl)); grid = dim3(256); block = dim3(768); }
+        else { kern = (s->dbg & 0x800000) ? k_nonbonded_f3t128 : ((s->dbg & 0x4000000) ? k_nonbonded_f3t : k_nonbonded_f3tl); grid = dim3(256); block = dim3(768); }
     } else if (wv == 4 && s->gtab && !(s->dbg & 0x400000)) { kern = k_nonbonded_f4tl4; grid = dim3(256); block = dim3(1024); }
     hipExtLaunchKernelGGL(kern, grid, block, 0, s->stream, ev_a, ev_b, 0, A);
     MDX_CHECK(s, hipGetLastError());
