@@ -40,6 +40,11 @@ struct NbArgs {
     long long *wave_t;           // diagnostic: per wave (start clock, end clock, wall start, wall end, units, entries)
 };
 
+// Element `idx` of an array of at most 4 GB through a 32-bit byte offset: the access then takes the uniform base from
+// scalar registers and one lane offset register, with no 64-bit address arithmetic on the vector unit.
+template <class T> __device__ __forceinline__ T *at32(T *base, unsigned idx) { return (T *)((char *)base + idx * (unsigned)sizeof(T)); }
+template <class T> __device__ __forceinline__ const T *at32(const T *base, unsigned idx) { return (const T *)((const char *)base + idx * (unsigned)sizeof(T)); }
+
 // Cross-lane adds inside groups of 8 consecutive lanes as DPP moves (no LDS crossbar traffic).
 __device__ __forceinline__ float dpp_quad_x1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)); }
 __device__ __forceinline__ float dpp_quad_x2(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)); }
@@ -75,7 +80,7 @@ __device__ __forceinline__ float mdx_pmecorr(float w)
 
 // Second-generation kernel: the <= 32 list entries of a work unit are fetched with one coalesced
 // load and broadcast with v_readlane, the j-atoms of entry e+1 are requested before entry e is
-// evaluated, two j-clusters share one 48-lane float atomic, and the force-only variant replaces
+// evaluated, and the force-only variant replaces
 // exp + erfc by the rational Ewald correction above.
 // ABL bits: 1, 2 remove arithmetic (timing experiments); 4 takes the Ewald correction g from the table `gtab` in LDS;
 // 8 (energy kernel) takes g and h = erf(z)/z from a float4 table.
@@ -156,11 +161,11 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
         if (ILDS) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // the previous pass has read its values
         float fix[NI], fiy[NI], fiz[NI];
         // (one load and one LDS store per wave: lane l brings the pair of the l-th i-atom)
-        if (ILDS && lane < NI * 8) myilj[lane] = A.lj_s[(sci * 8 + c0) * 8 + lane];
+        if (ILDS && lane < NI * 8) myilj[lane] = *at32(A.lj_s, (unsigned)((sci * 8 + c0) * 8 + lane));
 #pragma unroll
         for (int c = 0; c < NI; c++) {
             const int ia = (sci * 8 + c0 + c) * 8 + ti;
-            const float4 p = A.xq_s[ia];
+            const float4 p = *at32(A.xq_s, (unsigned)ia);
             xi[c] = p.x - S.x; yi[c] = p.y - S.y; zi[c] = p.z - S.z;
             qi[c] = p.w * MDX_ONE_4PI_EPS0;
             if (!ILDS) { const float2 l = A.lj_s[ia]; hsi[c] = l.x; sei[c] = l.y; }
@@ -171,12 +176,12 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
         if (ILDS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         // Software pipeline over the entries: j-atoms and exclusion mask are requested one entry ahead
         int cj_n = __builtin_amdgcn_readlane(myent.cj, 0);
-        float4 pj_n = A.xq_s[cj_n * 8 + tj];
-        float2 lj_n = A.lj_s[cj_n * 8 + tj];
+        // (unsigned element indices: a uniform base plus a zero-extended 32-bit lane offset needs no 64-bit address arithmetic)
+        float4 pj_n = *at32(A.xq_s, (unsigned)(cj_n * 8 + tj));
+        float2 lj_n = *at32(A.lj_s, (unsigned)(cj_n * 8 + tj));
         unsigned mk_n = (unsigned)__builtin_amdgcn_readlane((int)myent.mask, 0);
         unsigned ex_n = 0xFFu;
-        if (mk_n >> 8) ex_n = A.exclmask[(size_t)(mk_n >> 8) * 64 + lane];
-        float hold = 0.0f; int hold_addr = 0; bool hold_did = false;
+        if (mk_n >> 8) ex_n = A.exclmask[(mk_n >> 8) * 64u + (unsigned)lane];
         for (int e = 0; e < count; e++) {
             const int cj = cj_n;
             const float4 pj = pj_n;
@@ -185,11 +190,11 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
             const unsigned ex = ex_n;
             if (e + 1 < count) {
                 cj_n = __builtin_amdgcn_readlane(myent.cj, e + 1);
-                pj_n = A.xq_s[cj_n * 8 + tj];
-                lj_n = A.lj_s[cj_n * 8 + tj];
+                pj_n = *at32(A.xq_s, (unsigned)(cj_n * 8 + tj));
+                lj_n = *at32(A.lj_s, (unsigned)(cj_n * 8 + tj));
                 mk_n = (unsigned)__builtin_amdgcn_readlane((int)myent.mask, e + 1);
                 ex_n = 0xFFu;
-                if (mk_n >> 8) ex_n = A.exclmask[(size_t)(mk_n >> 8) * 64 + lane];
+                if (mk_n >> 8) ex_n = A.exclmask[(mk_n >> 8) * 64u + (unsigned)lane];
             }
             const unsigned imask = ((mk & 0xFFu) >> c0) & ((1u << NI) - 1u);
             const unsigned slot = mk >> 8;
@@ -316,23 +321,9 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
             asm volatile("" :: "v"(pj_n.x), "v"(pj_n.y), "v"(pj_n.z), "v"(pj_n.w), "v"(lj_n.x), "v"(lj_n.y), "v"(ex_n));
             // an entry none of whose tiles had a pair inside the cutoff has no j-force to reduce or add
             if (did && !(ABL & 2)) { fjx = sum8(fjx); fjy = sum8(fjy); fjz = sum8(fjz); }
-            const int ja3 = 3 * (cj * 8 + tj);
-            if (((e & 1) == 0) && (e + 1 < count)) {
-                // keep this cluster's components on lanes ti = 0..2 until the next one is ready
-                hold = (ti == 0) ? fjx : ((ti == 1) ? fjy : fjz);
-                hold_addr = ja3 + ti;
-                hold_did = did;
-            } else if (e & 1) {
-                if (did || hold_did) {
-                    const float cur = (ti == 3) ? fjx : ((ti == 4) ? fjy : fjz);
-                    const float val = (ti < 3) ? hold : cur;
-                    const int addr = (ti < 3) ? hold_addr : ja3 + ti - 3;
-                    const bool mine = (ti < 3) ? hold_did : (did && ti < 6);
-                    if (mine && !(A.dbg & 0x20000)) atomicAdd(&A.f_s[addr], val);
-                }
-            } else {
-                if (did && ti < 3 && !(A.dbg & 0x20000)) atomicAdd(&A.f_s[ja3 + ti], (ti == 0) ? fjx : ((ti == 1) ? fjy : fjz));
-            }
+            // (one 24-lane atomic per entry: pairing two entries into one 48-lane atomic costs more VALU instructions in
+            // the selects than the second atomic costs now that no wait sits behind it)
+            if (did && ti < 3 && !(A.dbg & 0x20000)) atomicAdd(at32(A.f_s, (unsigned)(3 * (cj * 8 + tj) + ti)), (ti == 0) ? fjx : ((ti == 1) ? fjy : fjz));
         }
 #pragma unroll
         for (int c = 0; c < NI; c++) {
@@ -342,7 +333,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
             ax += __shfl_xor(ax, 32, 64); ay += __shfl_xor(ay, 32, 64); az += __shfl_xor(az, 32, 64);
             if (tj < 3 && !(A.dbg & 0x40000)) {
                 const float val = (tj == 0) ? ax : ((tj == 1) ? ay : az);
-                atomicAdd(&A.f_s[3 * ((sci * 8 + c0 + c) * 8 + ti) + tj], val);
+                atomicAdd(at32(A.f_s, (unsigned)(3 * ((sci * 8 + c0 + c) * 8 + ti) + tj)), val);
             }
         }
         }
@@ -400,7 +391,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 // The same with the i-atoms' LJ parameters in LDS: 16 registers fewer, so that three such waves leave a SIMD room for
 // three waves of the co-running PME and bonded kernels instead of two.
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3tl(NbArgs A)
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_f3tl(NbArgs A)
 {
     __shared__ float4 tab4[MDX_GTAB_N / 2];
     __shared__ float2 ilj[12 * 64];
