@@ -174,28 +174,24 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
         // (LDS operations of one wave execute in order; the fence only keeps the compiler from moving the reads of
         // other lanes' values above the writes)
         if (ILDS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        // Software pipeline over the entries: j-atoms and exclusion mask are requested one entry ahead
-        int cj_n = __builtin_amdgcn_readlane(myent.cj, 0);
+        // Software pipeline over the entries: j-atoms and exclusion mask are requested one entry ahead, into two register
+        // sets used in turn (the loop is unrolled by two by hand, so that no set is copied into the other).
         // (unsigned element indices: a uniform base plus a zero-extended 32-bit lane offset needs no 64-bit address arithmetic)
-        float4 pj_n = *at32(A.xq_s, (unsigned)(cj_n * 8 + tj));
-        float2 lj_n = *at32(A.lj_s, (unsigned)(cj_n * 8 + tj));
-        unsigned mk_n = (unsigned)__builtin_amdgcn_readlane((int)myent.mask, 0);
-        unsigned ex_n = 0xFFu;
-        if (mk_n >> 8) ex_n = A.exclmask[(mk_n >> 8) * 64u + (unsigned)lane];
-        for (int e = 0; e < count; e++) {
-            const int cj = cj_n;
-            const float4 pj = pj_n;
-            const float2 lj = lj_n;
-            const unsigned mk = mk_n;
-            const unsigned ex = ex_n;
-            if (e + 1 < count) {
-                cj_n = __builtin_amdgcn_readlane(myent.cj, e + 1);
-                pj_n = *at32(A.xq_s, (unsigned)(cj_n * 8 + tj));
-                lj_n = *at32(A.lj_s, (unsigned)(cj_n * 8 + tj));
-                mk_n = (unsigned)__builtin_amdgcn_readlane((int)myent.mask, e + 1);
-                ex_n = 0xFFu;
-                if (mk_n >> 8) ex_n = A.exclmask[(mk_n >> 8) * 64u + (unsigned)lane];
-            }
+        struct JSet { int cj; float4 pj; float2 lj; unsigned mk; unsigned ex; };
+        auto fetch = [&](JSet &J, const int e) {
+            J.cj = __builtin_amdgcn_readlane(myent.cj, e);
+            J.pj = *at32(A.xq_s, (unsigned)(J.cj * 8 + tj));
+            J.lj = *at32(A.lj_s, (unsigned)(J.cj * 8 + tj));
+            J.mk = (unsigned)__builtin_amdgcn_readlane((int)myent.mask, e);
+            J.ex = 0xFFu;
+            if (J.mk >> 8) J.ex = A.exclmask[(J.mk >> 8) * 64u + (unsigned)lane];
+        };
+        auto entry = [&](const JSet &J, const JSet &N) {
+            const int cj = J.cj;
+            const float4 pj = J.pj;
+            const float2 lj = J.lj;
+            const unsigned mk = J.mk;
+            const unsigned ex = J.ex;
             const unsigned imask = ((mk & 0xFFu) >> c0) & ((1u << NI) - 1u);
             const unsigned slot = mk >> 8;
             // `live` bit c: this lane's pair with i-cluster c is evaluated at all. In the tile of a
@@ -318,12 +314,22 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
             // The wave waits for the next entry's j-atoms here, ahead of this entry's force atomics: memory operations
             // retire in order, so a wait placed behind the atomics (where the values are first used) would also wait for
             // the atomics to reach the L2, once per entry.
-            asm volatile("" :: "v"(pj_n.x), "v"(pj_n.y), "v"(pj_n.z), "v"(pj_n.w), "v"(lj_n.x), "v"(lj_n.y), "v"(ex_n));
+            asm volatile("" :: "v"(N.pj.x), "v"(N.pj.y), "v"(N.pj.z), "v"(N.pj.w), "v"(N.lj.x), "v"(N.lj.y), "v"(N.ex));
             // an entry none of whose tiles had a pair inside the cutoff has no j-force to reduce or add
             if (did && !(ABL & 2)) { fjx = sum8(fjx); fjy = sum8(fjy); fjz = sum8(fjz); }
             // (one 24-lane atomic per entry: pairing two entries into one 48-lane atomic costs more VALU instructions in
             // the selects than the second atomic costs now that no wait sits behind it)
             if (did && ti < 3 && !(A.dbg & 0x20000)) atomicAdd(at32(A.f_s, (unsigned)(3 * (cj * 8 + tj) + ti)), (ti == 0) ? fjx : ((ti == 1) ? fjy : fjz));
+        };
+        JSet Ja, Jb;
+        fetch(Ja, 0);
+        Jb = Ja;
+        for (int e = 0; e < count; e += 2) {
+            if (e + 1 < count) fetch(Jb, e + 1);
+            entry(Ja, Jb);
+            if (e + 1 >= count) break;
+            if (e + 2 < count) fetch(Ja, e + 2);
+            entry(Jb, Ja);
         }
 #pragma unroll
         for (int c = 0; c < NI; c++) {
