@@ -167,7 +167,7 @@ def main():
     ap.add_argument("--box", type=float, default=12.5)
     ap.add_argument("--workload", default="production", choices=["production", "smd", "dd"],
                     help="dd: the tiled ~1.1 M-atom water box decomposed over the N GPUs (strong scaling); not the default")
-    ap.add_argument("--pcoupl", default="c-rescale", choices=["c-rescale", "parrinello-rahman", "no"])
+    ap.add_argument("--pcoupl", default="parrinello-rahman", choices=["c-rescale", "parrinello-rahman", "no"])      # production.mdp:36
     ap.add_argument("--nstlist", type=int, default=20,
                     help="pair-list lifetime; the .mdp value 10 is a lower bound that mdrun raises on GPUs")
     ap.add_argument("--cpu-steps", type=int, default=50, help="steps of the CPU baseline per thread count")
@@ -312,12 +312,15 @@ def main():
         peak = 157.3
         # HBM bytes per launch of the nonbonded kernel from the PMC passes kept under profiles/
         # (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc runs; not collected live)
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01", "nb_pmc_traffic.json")) as f:
-                traffic = float(json.load(f)["hbm_bytes_per_launch"])
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic, traffic_src = None, None
+        for rnd in ("r02", "r01"):          # the newest collection that is present
+            try:
+                with open(os.path.join(ROOT, "profiles", rnd, "nb_pmc_traffic.json")) as f:
+                    traffic = float(json.load(f)["hbm_bytes_per_launch"])
+                traffic_src = "profiles/%s/nb_pmc_traffic.json" % rnd
+                break
+            except (OSError, KeyError, ValueError):
+                pass
         out = {
             "metric": "ns/day", "value": round(ns_day, 3), "unit": "ns/day", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 5), "higher_is_better": True,
@@ -338,7 +341,7 @@ def main():
             "pair_interactions_per_s_end_to_end": round(n_rc * args.steps / elapsed_max * world, 1),
             "roofline": {"bound": "valu_f32", "kernel": "k_nonbonded", "achieved": round(achieved, 3), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (separate rocprofv3 --pmc passes on this workload; profiles/r01/nb_pmc_traffic.json)",
+                         "traffic_unit": "HBM bytes per launch (separate rocprofv3 --pmc passes on this workload; %s)" % traffic_src,
                          "peak_unpacked": 78.6, "frac_unpacked": round(achieved / 78.6, 4),
                          "flops_per_launch": flops, "pairs_within_rc": n_rc, "pairs_with_lj": n_lj,
                          "avg_launch_ms": round(nb_avg_s * 1e3, 5), "launches": nb_launches,
