@@ -182,8 +182,7 @@ __global__ __launch_bounds__(256) void k_pme_spread_chunk(SpreadChunkArgs A, con
     MDX_STAMP_ALL(d, 3);
     extern __shared__ float tile[];
     int *ox = (int *)(tile + A.PPC * A.T1 * A.T0);
-    int *oy = ox + A.PPC;
-    __shared__ int s_tp0;
+    int *oy = ox + A.PPC, *oxw = oy + A.PPC, *oyw = oxw + A.PPC;      // window origins per plane: as computed, and wrapped into the grid
     const int col = blockIdx.x;
     const int sc_first = A.col_scstart[col] + blockIdx.y * A.sc_per_chunk;
     const int sc_end = min(A.col_scstart[col + 1], sc_first + A.sc_per_chunk);
@@ -202,6 +201,7 @@ __global__ __launch_bounds__(256) void k_pme_spread_chunk(SpreadChunkArgs A, con
         const float ux = A.K0 * (x_lo * bx.inv[0] + fminf(y_lo * bx.inv[3], y_hi * bx.inv[3]) + fminf(z_lo * bx.inv[6], z_hi * bx.inv[6]));
         const float uy = A.K1 * (y_lo * bx.inv[4] + fminf(z_lo * bx.inv[7], z_hi * bx.inv[7]));
         ox[p] = (int)floorf(ux); oy[p] = (int)floorf(uy);
+        oxw[p] = pmod(ox[p], A.K0); oyw[p] = pmod(oy[p], A.K1);
     }
     const int nt = A.PPC * A.T1 * A.T0;
 #pragma unroll 1
@@ -256,14 +256,24 @@ __global__ __launch_bounds__(256) void k_pme_spread_chunk(SpreadChunkArgs A, con
         }
     }
     __syncthreads();
+    // Flush of the non-zero window points. A thread keeps its (rx, ry) inside the plane window and walks the planes,
+    // so the index arithmetic of a point is a few additions (divisions only once per thread and window position).
+    const int t01 = A.T0 * A.T1;
+    const int gz0 = pmod(tp0 - 3, A.K2);
 #pragma unroll 1
-    for (int k = threadIdx.x; k < nt; k += blockDim.x) {
-        const int vi = ((const int *)tile)[k];
-        if (vi == 0) continue;
-        const float v = (float)vi * (1.0f / MDX_SPREAD_SCALE);
-        const int rx = k % A.T0, ry = (k / A.T0) % A.T1, pl = k / (A.T0 * A.T1);
-        const int gz = pmod(tp0 + pl - 3, A.K2), gy = pmod(oy[pl] + ry, A.K1), gx = pmod(ox[pl] + rx, A.K0);
-        atomicAdd(&A.grid[((size_t)gz * A.K1 + gy) * A.K0 + gx], v);
+    for (int i = threadIdx.x; i < t01; i += blockDim.x) {
+        const int ry = i / A.T0, rx = i - ry * A.T0;
+        int gz = gz0;
+#pragma unroll 1
+        for (int pl = 0; pl < A.PPC; pl++) {
+            const int vi = ((const int *)tile)[pl * t01 + i];
+            if (vi != 0) {
+                int gx = oxw[pl] + rx, gy = oyw[pl] + ry;
+                gx -= gx >= A.K0 ? A.K0 : 0; gy -= gy >= A.K1 ? A.K1 : 0;
+                atomicAdd(&A.grid[((size_t)gz * A.K1 + gy) * A.K0 + gx], (float)vi * (1.0f / MDX_SPREAD_SCALE));
+            }
+            gz++; gz -= gz >= A.K2 ? A.K2 : 0;
+        }
     }
 }
 
@@ -774,7 +784,7 @@ int mdx_launch_pme_spread(mdx_system *s, hipStream_t st, bool signal)
             C.PPC = std::min(K2 + 8, (int)ceil((C.sc_per_chunk * sc_h * 1.15 + 2 * delta) * K2 * inv8) + 5);
             while ((size_t)C.PPC * C.T0 * C.T1 * 4 > 60 * 1024 && C.PPC > 8) C.PPC--;
             C.delta = (float)delta; C.grid = s->grid; C.v_home = s->dd_on ? s->v : nullptr;
-            const size_t ldsc = (size_t)C.PPC * C.T0 * C.T1 * 4 + (size_t)C.PPC * 8;
+            const size_t ldsc = (size_t)C.PPC * C.T0 * C.T1 * 4 + (size_t)C.PPC * 16;
             // columns hold at most MDX_MAX_COL atoms = 32 super-clusters
             const int ychunks = (MDX_MAX_COL / 64 + C.sc_per_chunk - 1) / C.sc_per_chunk;
             hipLaunchKernelGGL(k_pme_spread_chunk, dim3(s->ncx * s->ncy, ychunks), dim3(256), ldsc, st, C, (const DevState *)s->d);

@@ -45,6 +45,30 @@ class MdxError(RuntimeError):
     pass
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process. A PyTorch-ROCm wheel ships its own libamdhip64.so; libmdx.so names the system one.
+    Both have the same SONAME, so whichever is loaded first serves both — unless libmdx.so comes first, in which case
+    torch still loads its bundled copy by path, the process holds two runtimes and torch then reports "No HIP GPUs are
+    available". Loading torch's copy (when a torch installation has one) ahead of libmdx.so makes the order irrelevant.
+    Nothing is imported from torch; without torch the system runtime is used."""
+    try:
+        with open("/proc/self/maps") as f:
+            if "libamdhip64" in f.read():
+                return                      # a runtime is already in the process: libmdx.so binds to it
+    except OSError:
+        pass
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except (ImportError, OSError, ValueError):
+        pass
+
+
 def load_library(path: str | None = None):
     """Load libmdx.so and declare the C signatures. Raises if the library is missing."""
     global _LIB
@@ -54,6 +78,7 @@ def load_library(path: str | None = None):
     if not os.path.exists(p):
         raise MdxError(f"{p} not found: build it with `make -C molecular-dynamics_amd/csrc` "
                        "(the engine has no CPU fallback)")
+    _share_torch_hip_runtime()
     L = ctypes.CDLL(p)
     c_int, c_f, c_d, vp = ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
     fp, ip, dp = ctypes.POINTER(c_f), ctypes.POINTER(c_int), ctypes.POINTER(c_d)

@@ -36,3 +36,12 @@ def test_two_processes_share_one_gpu_at_normal_speed(tmp_path):
     assert res["n_shared"] > 20 and new["chunks"] == 60
     # nobody crawled: a 10-step chunk of this 17 k-atom box takes a few milliseconds; the pathological case is >0.5 s
     assert new["worst_chunk_s"] < 0.25 and res["worst_chunk_s"] < 0.25, (res["worst_chunk_s"], new["worst_chunk_s"])
+
+
+def test_torch_reaches_the_gpu_after_the_engine_was_loaded_first():
+    """One HIP runtime per process: the engine's loader brings in the runtime a PyTorch-ROCm installation ships before
+    libmdx.so, so that a program that creates an engine first and touches torch.cuda afterwards does not end up with
+    two runtimes (torch then reports "No HIP GPUs are available")."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hip_runtime_order.py")], capture_output=True, text=True, timeout=150)
+    assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+    assert "torch on the GPU after the engine: ok" in p.stdout, p.stdout[-2000:]
