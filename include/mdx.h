@@ -254,6 +254,22 @@ int mdx_dd_step_end(mdx_system *sys);
 int mdx_dd_grid(mdx_system *sys, void **grid_dev, long long *nelem);
 int mdx_dd_stream_sync(mdx_system *sys);
 int mdx_dd_state_pointers(mdx_system *sys, void **x4_dev, void **v4_dev);
+/* Quantities the domains have to agree on. Energy steps: every domain's energy terms, virial and pressure are
+ * partial sums over the atoms it owns (a pair with a halo atom counts half on each side, the Ewald self term covers
+ * the home atoms) and add up over the domains; the reciprocal-space energy and virial are the same on every domain,
+ * so mdx_dd_set_roles(sys, mesh_energy, own_tcouple) lets one domain report them (mesh_energy = 0 elsewhere).
+ * own_tcouple = 0: mdx_dd_step_end computes the half-step kinetic energy of the home atoms on thermostat steps but
+ * leaves the V-rescale factor alone; the caller sums the MDX_MAX_TC doubles at `ekinh_dev` (mdx_dd_scalars) over the
+ * domains and calls mdx_dd_tcouple, so that all domains (same seed, ndf of mdx_dd_load = that of the whole system)
+ * scale by one factor. Centre-of-mass removal: mdx_dd_com(sys, 0) sums m v and m of the home atoms into the 4 doubles
+ * at `com_dev`, the caller sums them over the domains, mdx_dd_com(sys, 1) subtracts the common velocity.
+ * mdx_dd_kinetic puts the current half-step kinetic energy of the home atoms into the scalars (with own_tcouple = 0 the
+ * caller draws the factor of the first steps from it: mdx_dd_kinetic, sum, mdx_dd_tcouple(sys, 1)). */
+int mdx_dd_set_roles(mdx_system *sys, int mesh_energy, int own_tcouple);
+int mdx_dd_scalars(mdx_system *sys, void **ekinh_dev, void **com_dev);
+int mdx_dd_tcouple(mdx_system *sys, int before_first_step);
+int mdx_dd_kinetic(mdx_system *sys);
+int mdx_dd_com(mdx_system *sys, int phase);
 /* Time the nonbonded kernel with HIP events on the handle's stream (bench only): on = n > 0 samples every n-th
  * force-only launch (a stride such as 7 does not lock onto the 10- and 20-step cadences of energy and search steps). */
 int mdx_enable_kernel_timing(mdx_system *sys, int on);

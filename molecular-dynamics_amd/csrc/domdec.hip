@@ -31,13 +31,16 @@ __global__ void k_dd_load(int ncap, int n_home, int n_total, const float4 *__res
         float4 w = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (i < n_home) { w = vin[i]; w.w = invm0[i]; }
         v[i] = w;
-        lj[i] = lj0[i];
+        // a halo atom carries a minus sign on 2 sqrt(eps) (also on a zero): the pair kernel takes the magnitude and, on
+        // energy steps, reads the sign as "not owned here"
+        const float2 l = lj0[i];
+        lj[i] = make_float2(l.x, i < n_home ? l.y : -fabsf(l.y));
     } else {
         // unused slot: no charge, no LJ well, parked on top of a real atom (the kernels keep r = 0 finite)
         const float4 p = xin[i % n_total];
         x[i] = make_float4(p.x, p.y, p.z, 0.0f);
         v[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        lj[i] = make_float2(lj0[i].x, 0.0f);
+        lj[i] = make_float2(lj0[i].x, -0.0f);
     }
 }
 
@@ -81,6 +84,9 @@ extern "C" int mdx_dd_load(mdx_system *s, int n_home, int n_total, const void *x
                        (const float4 *)v4_dev, (const float *)s->dd_q0, (const float *)s->dd_invm0, (const float2 *)s->dd_lj0, s->x, s->v, s->lj);
     MDX_CHECK(s, hipGetLastError());
     s->dd_on = true;
+    // Ewald self term of the atoms this domain owns
+    s->q2sum = 0.0;
+    for (int i = 0; i < n_home; i++) s->q2sum += (double)s->host_atoms.q[i] * s->host_atoms.q[i];
     s->nsettle = n_settle;
     s->search_density = density;
     s->steps_since_search = 1 << 30;
@@ -133,6 +139,56 @@ extern "C" int mdx_dd_step_end(mdx_system *s)
     (void)hipSetDevice(s->device);
     if (!s->dd_on) { s->err = "mdx_dd_step_end: no partition loaded"; return MDX_ERR_ARG; }
     return mdx_step_end_internal(s);
+}
+
+// Which parts of a step this domain's handle does on its own (default: all of them, as a single domain needs):
+//   mesh_energy 0: the reciprocal-space energy and virial are not accumulated here (every domain solves the same mesh
+//                  problem; one of them reports it);
+//   own_tcouple 0: mdx_dd_step_end leaves the thermostat factor alone; the caller sums the half-step kinetic energies of
+//                  all domains into the scalars of mdx_dd_scalars and calls mdx_dd_tcouple, so that every domain scales
+//                  by the same factor (same seed on every domain).
+extern "C" int mdx_dd_set_roles(mdx_system *s, int mesh_energy, int own_tcouple)
+{
+    s->dd_mesh_energy = mesh_energy != 0;
+    s->dd_own_tcouple = own_tcouple != 0;
+    return MDX_OK;
+}
+
+// Device pointers of the scalars the domains have to agree on: the half-step kinetic energy per temperature-coupling
+// group (MDX_MAX_TC doubles) and the momentum sum of the centre-of-mass removal (4 doubles: m v and m).
+extern "C" int mdx_dd_scalars(mdx_system *s, void **ekinh_dev, void **com_dev)
+{
+    if (ekinh_dev) *ekinh_dev = (char *)s->d + offsetof(DevState, ekinh);
+    if (com_dev) *com_dev = (char *)s->d + offsetof(DevState, com_v);
+    return MDX_OK;
+}
+
+// The thermostat factor for the coming steps from the (summed) kinetic energy in the handle's scalars.
+extern "C" int mdx_dd_tcouple(mdx_system *s, int before_first_step)
+{
+    (void)hipSetDevice(s->device);
+    // the random stream of the factor is keyed as inside mdx_step: by the step just completed, or by the step about to
+    // start for the factor drawn ahead of the first one
+    if (!before_first_step) s->step--;
+    const int rc = mdx_launch_tcouple(s);
+    if (!before_first_step) s->step++;
+    return rc;
+}
+
+// Kinetic energy of the home atoms at the current half step into the handle's scalars (cleared first).
+extern "C" int mdx_dd_kinetic(mdx_system *s)
+{
+    (void)hipSetDevice(s->device);
+    int rc = mdx_launch_clear(s, false, true, false); if (rc) return rc;
+    return mdx_launch_ke(s, false, false);
+}
+
+// Centre-of-mass motion removal in two halves: sum m v and m of the home atoms into the scalars, then (after the
+// caller's sum over domains) subtract the common velocity.
+extern "C" int mdx_dd_com(mdx_system *s, int phase)
+{
+    (void)hipSetDevice(s->device);
+    return mdx_launch_comm_phase(s, phase);
 }
 
 // Device pointer and element count of the real-space charge grid (x fastest), for the caller's sum over domains.

@@ -848,7 +848,7 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early)
     const bool need_vir = do_ener || do_pc;
     const bool tc_apply = s->ntc > 0 && (step % s->nsttcouple == 0);
     if (phase != 2) {
-        if (s->first_step && s->ntc > 0) {
+        if (s->first_step && s->ntc > 0 && !(s->dd_on && !s->dd_own_tcouple)) {
             if ((rc = mdx_launch_clear(s, false, true, false))) return rc;
             if ((rc = mdx_launch_ke(s, false, false))) return rc;
             if ((rc = mdx_launch_tcouple(s))) return rc;
@@ -882,7 +882,7 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early)
         }
         if (phase == 1) return MDX_OK;
     }
-    if (phase == 2) if ((rc = mdx_launch_pme(s, need_vir, true))) return rc;
+    if (phase == 2) if ((rc = mdx_launch_pme(s, need_vir && s->dd_mesh_energy, true))) return rc;
     if (phase == 0 && s->rotate_streams && s->have_pme && !s->gather_on_main && !s->spread_on_main) {
         // The PME chain ends about when the nonbonded kernel does. A stream that waits for an event of another one
         // resumes several microseconds after it fires; the update is therefore enqueued behind the gather on the
@@ -925,7 +925,8 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early)
             if ((rc = mdx_launch_clear(s, false, true, false))) return rc;
             if ((rc = mdx_launch_ke(s, false, false))) return rc;
         }
-        if ((rc = mdx_launch_tcouple(s))) return rc;
+        // (a domain of a decomposed run may leave the factor to the caller, who sums the kinetic energies first)
+        if (!(s->dd_on && !s->dd_own_tcouple)) if ((rc = mdx_launch_tcouple(s))) return rc;
     }
     if (s->nstcomm > 0 && ((step + 1) % s->nstcomm == 0)) if ((rc = mdx_launch_comm(s))) return rc;
     s->step++;

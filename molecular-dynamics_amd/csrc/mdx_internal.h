@@ -242,6 +242,8 @@ struct mdx_system {
     double nb_ms_total = 0; long long nb_launches = 0;
     // domain decomposition (csrc/domdec.hip)
     bool dd_on = false;
+    bool dd_mesh_energy = true;        // this domain accumulates the reciprocal-space energy and virial
+    bool dd_own_tcouple = true;        // the step computes the thermostat factor itself (false: mdx_dd_tcouple after the caller's sum)
     float *dd_q0 = nullptr, *dd_invm0 = nullptr; float2 *dd_lj0 = nullptr;   // per-slot pattern as set up
     double search_density = 0.0;  // atoms per nm^3 for the sizing of the search grid (0: atoms / box volume)
     void *frame_ring = nullptr;   // pinned trajectory-frame slots (runctl.hip)
@@ -273,6 +275,9 @@ int mdx_launch_update(mdx_system *s, bool do_tc, bool do_pr, bool virial);
 int mdx_launch_constrain(mdx_system *s, float inv_dt, bool virial, int lincs_iter);
 void mdx_frames_free(mdx_system *s);
 int mdx_launch_ke(mdx_system *s, bool old_slot, bool tensor, hipStream_t st = nullptr);
+int mdx_launch_comm_phase(mdx_system *s, int phase);
+int mdx_launch_clear(mdx_system *s, bool energies, bool ekin_new, bool ekin_old);
+int mdx_launch_tcouple(mdx_system *s);
 int mdx_launch_clear(mdx_system *s, bool energies, bool ekin_new, bool ekin_old);
 int mdx_launch_tcouple(mdx_system *s);
 int mdx_launch_pcouple(mdx_system *s);

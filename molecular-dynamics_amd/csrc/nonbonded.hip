@@ -230,7 +230,8 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                 float hs_c, se_c;
                 if (ILDS) { const float2 li = myilj[c * 8 + ti]; hs_c = li.x; se_c = li.y; } else { hs_c = hsi[c]; se_c = sei[c]; }
                 const float sg = hs_c + lj.x;
-                const float e4 = se_c * lj.y;
+                // (a negative sign on 2 sqrt(eps), zero included, marks an atom that another domain owns: domain decomposition)
+                const float e4 = fabsf(se_c) * fabsf(lj.y);
                 const float s2 = sg * sg * rinv2;
                 const float s6 = s2 * s2 * s2;
                 const float t6 = e4 * s6;
@@ -284,6 +285,9 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                 fix[c] += fx; fiy[c] += fy; fiz[c] += fz;
                 fjx -= fx; fjy -= fy; fjz -= fz;
                 if (ENERGY) {
+                    // A pair between an atom of this domain and a copy of another domain's atom is evaluated by both
+                    // owners: each takes half of its energy and virial; a pair of two copies belongs to others entirely.
+                    const float wgt = 1.0f - 0.5f * (float)((__float_as_uint(se_c) >> 31) + (__float_as_uint(lj.y) >> 31));
                     {
                         // statistics: pairs of real atoms (a filler carries a negative half-sigma) inside the cutoff
                         const bool counted = within && listed && hs_c >= 0.0f && lj.x >= 0.0f;
@@ -293,13 +297,14 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                     if (within && listed) {
                         const float c2 = sg * sg * (1.0f / rc2);
                         const float c6 = c2 * c2 * c2;
-                        elj += t6 * (s6 - 1.0f) - e4 * c6 * (c6 - 1.0f);
-                        ecoul += qq * (erfc_br * rinv - A.c_rf_shift);
+                        elj = fmaf(wgt, t6 * (s6 - 1.0f) - e4 * c6 * (c6 - 1.0f), elj);
+                        ecoul = fmaf(wgt, qq * (erfc_br * rinv - A.c_rf_shift), ecoul);
                     } else if (within) {
-                        eexcl += e_ex;
+                        eexcl = fmaf(wgt, e_ex, eexcl);
                     }
-                    vxx = fmaf(dx, fx, vxx); vxy = fmaf(dx, fy, vxy); vxz = fmaf(dx, fz, vxz);
-                    vyy = fmaf(dy, fy, vyy); vyz = fmaf(dy, fz, vyz); vzz = fmaf(dz, fz, vzz);
+                    const float wx = wgt * fx, wy = wgt * fy, wz = wgt * fz;
+                    vxx = fmaf(dx, wx, vxx); vxy = fmaf(dx, wy, vxy); vxz = fmaf(dx, wz, vxz);
+                    vyy = fmaf(dy, wy, vyy); vyz = fmaf(dy, wz, vyz); vzz = fmaf(dz, wz, vzz);
                 }
             };
             if (!general) {

@@ -607,14 +607,21 @@ int mdx_launch_pcouple(mdx_system *s)
     return MDX_OK;
 }
 
-int mdx_launch_comm(mdx_system *s)
+// phase 0: momentum and mass sums into DevState::com_v; phase 1: subtract the common velocity
+int mdx_launch_comm_phase(mdx_system *s, int phase)
 {
     const int nb = (s->n + 255) / 256;
-    MDX_CHECK(s, hipMemsetAsync((char *)s->d + offsetof(DevState, com_v), 0, sizeof(double) * 4, s->stream));
-    hipLaunchKernelGGL(k_comm_sum, dim3(nb), dim3(256), 0, s->stream, s->n, s->v, s->d);
-    hipLaunchKernelGGL(k_comm_sub, dim3(nb), dim3(256), 0, s->stream, s->n, s->v, s->d);
+    if (phase == 0) {
+        MDX_CHECK(s, hipMemsetAsync((char *)s->d + offsetof(DevState, com_v), 0, sizeof(double) * 4, s->stream));
+        hipLaunchKernelGGL(k_comm_sum, dim3(nb), dim3(256), 0, s->stream, s->n, s->v, s->d);
+    } else hipLaunchKernelGGL(k_comm_sub, dim3(nb), dim3(256), 0, s->stream, s->n, s->v, s->d);
     MDX_CHECK(s, hipGetLastError());
     return MDX_OK;
+}
+int mdx_launch_comm(mdx_system *s)
+{
+    int rc = mdx_launch_comm_phase(s, 0);
+    return rc ? rc : mdx_launch_comm_phase(s, 1);
 }
 
 int mdx_launch_merge_forces(mdx_system *s, float *out3n)

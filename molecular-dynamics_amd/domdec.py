@@ -284,7 +284,10 @@ class DecomposedWater:
     def __init__(self, sysm: MDSystem, device: int = 0, rc: float = 1.0, dt: float = 0.002, nstlist: int = 20,
                  ref_t: float | None = 300.0, tau_t: float = 0.1, nsttcouple: int = 10, fourierspacing: float = 0.16,
                  rlist: float | None = None, seed: int = 1, group=None, dims=None, nstcalcenergy: int = 0,
-                 shared_device: bool = False, transport=None):
+                 transport=None, global_coupling: bool = True, nstcomm: int = 0):
+        """global_coupling: one V-rescale factor for the whole system from the kinetic energy summed over the domains
+        (every domain draws it from the same random stream); False: every domain is its own thermostat group.
+        nstcomm > 0: centre-of-mass motion of the whole system removed every nstcomm steps."""
         from . import engine as eng
         self.tr = transport if transport is not None else Transport(group)
         self.rank, self.world = self.tr.rank, self.tr.world
@@ -315,9 +318,18 @@ class DecomposedWater:
         grid = U.pme_grid(self.box_np, fourierspacing)
         self.engine = eng.Engine(tmpl, rc=rc, rlist=self.rlist, dt=dt, nstlist=nstlist, pme=True, grid=grid, device=device,
                                  tc_groups=["System"] if ref_t is not None else None, ref_t=[ref_t or 300.0], tau_t=[tau_t],
-                                 nsttcouple=nsttcouple, nstcalcenergy=nstcalcenergy, nstcomm=0, seed=seed + self.rank)
+                                 nsttcouple=nsttcouple, nstcalcenergy=nstcalcenergy, nstcomm=0,
+                                 seed=seed if global_coupling else seed + self.rank)
+        self.thermostat = ref_t is not None
+        self.global_coupling = bool(global_coupling)
+        self.nsttcouple, self.nstcomm, self.nstcalcenergy = int(nsttcouple), int(nstcomm), int(nstcalcenergy)
+        # the reciprocal-space energy is the same on every domain: the first one reports it
+        self.engine.dd_set_roles(self.rank == 0, not (self.global_coupling and self.thermostat))
         gp, gn = self.engine.dd_grid()
         self.grid_t = torch.as_tensor(_DevArray(gp, (gn,)), device=self.dev)
+        ep, cp = self.engine.dd_scalars()
+        self.ekinh_t = torch.as_tensor(_DevArray(ep, (8,), "<f8"), device=self.dev)
+        self.com_t = torch.as_tensor(_DevArray(cp, (4,), "<f8"), device=self.dev)
         # initial home set from the given coordinates
         x = torch.tensor(np.asarray(sysm.x, dtype=np.float32), device=self.dev).reshape(self.nmol, MOL_ATOMS, 3)
         v = torch.tensor(np.asarray(sysm.v if sysm.v is not None else np.zeros((n, 3)), dtype=np.float32), device=self.dev).reshape(self.nmol, MOL_ATOMS, 3)
@@ -358,7 +370,10 @@ class DecomposedWater:
         self.recv_buf = torch.zeros((sum(self.recv_counts), 4), device=self.dev, dtype=torch.float32)
         self._keep = (x4, v4)               # alive until the load kernel has run
         torch.cuda.synchronize(self.dev)
-        ndf = 6.0 * nh                       # rigid three-site molecules, no centre-of-mass removal
+        # degrees of freedom of rigid three-site molecules: the whole system's when the domains share one thermostat
+        # factor (a domain's temperature read-out is then its share of the total and the shares add up), the domain's own otherwise
+        self.ndf_global = 6.0 * self.nmol - (3.0 if self.nstcomm > 0 else 0.0)
+        ndf = self.ndf_global if self.global_coupling else 6.0 * nh
         self.engine.dd_load(MOL_ATOMS * nh, MOL_ATOMS * (nh + nl), x4.data_ptr(), v4.data_ptr(), nh, ndf, self.density)
 
     def _home_state(self):
@@ -426,7 +441,15 @@ class DecomposedWater:
         def say(what):
             if dbg:
                 print("[dd rank %d step %d] %s" % (self.rank, self.nsteps_done, what), flush=True)
+        shared_tc = self.thermostat and self.global_coupling
         for _ in range(int(nsteps)):
+            if shared_tc and self.nsteps_done == 0:
+                # the factor of the first steps, from the kinetic energy of the whole system
+                with self._exclusive():
+                    self.engine.dd_kinetic(); self.engine.dd_stream_sync()
+                self.tr.all_reduce_sum_(self.ekinh_t); torch.cuda.synchronize(self.dev)
+                with self._exclusive():
+                    self.engine.dd_tcouple(before_first_step=True)
             if self.steps_since_partition >= self.nstlist:
                 say("repartition"); self.repartition()
             elif self.steps_since_partition > 0:
@@ -440,11 +463,43 @@ class DecomposedWater:
                 torch.cuda.synchronize(self.dev)
             with self._exclusive():
                 say("end"); self.engine.dd_step_end()
+            done = self.nsteps_done + 1
+            if shared_tc and done % self.nsttcouple == 0:
+                # the step left the home atoms' half-step kinetic energy in the scalars: sum, then one factor for all
+                self.engine.dd_stream_sync()
+                self.tr.all_reduce_sum_(self.ekinh_t); torch.cuda.synchronize(self.dev)
+                with self._exclusive():
+                    self.engine.dd_tcouple()
+            if self.nstcomm > 0 and done % self.nstcomm == 0:
+                with self._exclusive():
+                    self.engine.dd_com(0); self.engine.dd_stream_sync()
+                self.tr.all_reduce_sum_(self.com_t); torch.cuda.synchronize(self.dev)
+                with self._exclusive():
+                    self.engine.dd_com(1)
             self.steps_since_partition += 1
             self.nsteps_done += 1
 
     def synchronize(self):
         self.engine.synchronize()
+
+    def energies(self):
+        """Energies, virial and pressure of the whole system at the last energy step (every rank gets the same numbers):
+        the domains' partial sums added up. Needs nstcalcenergy > 0."""
+        from . import engine as eng
+        e = self.engine.energies()
+        vir, pres = self.engine.virial()
+        names = ["LJ", "COUL_SR", "COUL_RECIP", "COUL_EXCL", "KIN", "TEMP", "PRES"]
+        vec = np.concatenate([[e[k] for k in names], vir.reshape(-1), pres.reshape(-1)])
+        if not self.global_coupling:
+            # a domain's temperature is over its own degrees of freedom: weight it back to a kinetic-energy share
+            vec[5] *= 6.0 * self.n_home / self.ndf_global
+        t = torch.tensor(vec, dtype=torch.float64, device=self.dev)
+        self.tr.all_reduce_sum_(t); torch.cuda.synchronize(self.dev)
+        vec = t.cpu().numpy()
+        out = {k: float(vec[i]) for i, k in enumerate(names)}
+        out["POT"] = out["LJ"] + out["COUL_SR"] + out["COUL_RECIP"] + out["COUL_EXCL"]
+        out["VOLUME"] = self.volume
+        return out, vec[7:16].reshape(3, 3), vec[16:25].reshape(3, 3)
 
     def gather_state(self):
         """Positions and velocities of the whole system, (N, 3) each, in the original molecule order (every rank)."""

@@ -34,7 +34,7 @@ SYMBOLS = [
     "mdx_synchronize", "mdx_get_list_stats", "mdx_pop_energy_frames", "mdx_pop_pull_records",
     "mdx_enable_kernel_timing", "mdx_get_kernel_timing", "mdx_debug_time_nonbonded", "mdx_debug_set", "mdx_debug_wave_times", "mdx_debug_stamps",
     "mdx_dd_load", "mdx_dd_pack", "mdx_dd_unpack", "mdx_dd_step_begin", "mdx_dd_wait_spread", "mdx_dd_step_end", "mdx_dd_grid",
-    "mdx_dd_stream_sync", "mdx_dd_state_pointers",
+    "mdx_dd_stream_sync", "mdx_dd_state_pointers", "mdx_dd_set_roles", "mdx_dd_scalars", "mdx_dd_tcouple", "mdx_dd_kinetic", "mdx_dd_com",
     "mdx_debug_time_stage", "mdx_set_step", "mdx_generate_velocities", "mdx_constrain_start", "mdx_minimize",
     "mdx_frame_ring", "mdx_capture_frame", "mdx_frame_wait",
 ]
@@ -132,6 +132,9 @@ def load_library(path: str | None = None):
     L.mdx_dd_grid.argtypes = [vp, ctypes.POINTER(vp), llp]
     L.mdx_dd_stream_sync.argtypes = [vp]
     L.mdx_dd_state_pointers.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
+    L.mdx_dd_set_roles.argtypes = [vp, c_int, c_int]
+    L.mdx_dd_scalars.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
+    L.mdx_dd_tcouple.argtypes = [vp, c_int]; L.mdx_dd_kinetic.argtypes = [vp]; L.mdx_dd_com.argtypes = [vp, c_int]
     L.mdx_debug_stamps.argtypes = [vp, c_int, ctypes.POINTER(ctypes.c_longlong)]
     L.mdx_debug_time_stage.argtypes = [vp, c_int, c_int, dp]
     L.mdx_set_step.argtypes = [vp, ctypes.c_longlong]
@@ -578,6 +581,24 @@ class Engine:
         x = ctypes.c_void_p(0); v = ctypes.c_void_p(0)
         self._call("mdx_dd_state_pointers", ctypes.byref(x), ctypes.byref(v))
         return x.value, v.value
+
+    def dd_set_roles(self, mesh_energy, own_tcouple):
+        self._call("mdx_dd_set_roles", int(bool(mesh_energy)), int(bool(own_tcouple)))
+
+    def dd_scalars(self):
+        """Device pointers of the half-step kinetic energies (8 doubles) and of the momentum sums (4 doubles)."""
+        a = ctypes.c_void_p(0); b = ctypes.c_void_p(0)
+        self._call("mdx_dd_scalars", ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
+
+    def dd_tcouple(self, before_first_step=False):
+        self._call("mdx_dd_tcouple", int(bool(before_first_step)))
+
+    def dd_kinetic(self):
+        self._call("mdx_dd_kinetic")
+
+    def dd_com(self, phase):
+        self._call("mdx_dd_com", int(phase))
 
     def debug_stamps(self, reset=False):
         buf = np.zeros((2, 24), dtype=np.int64)

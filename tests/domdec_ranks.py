@@ -32,6 +32,35 @@ def decomposed(world, nst, rest, d):
     return hub.run(rank_main)[0]
 
 
+def coupled(world, nst, d):
+    """Thermostat, centre-of-mass removal and energies across the domains against the single handle (same seed)."""
+    import mdx
+    from mdx import synth, domdec, engine as eng
+    hub = domdec.ThreadTransport.Hub(world)
+    kw = dict(rc=1.0, dt=0.002, nstlist=10, rlist=1.1)
+
+    def rank_main(rank, transport):
+        dd = domdec.DecomposedWater(synth.water_box(d=d), device=0, ref_t=300.0, tau_t=0.1, nsttcouple=10, nstcalcenergy=10,
+                                    nstcomm=10, seed=7, transport=transport, **kw)
+        dd.step(nst); dd.synchronize()
+        e, vir, pres = dd.energies()
+        x, v = dd.gather_state()
+        dd.close()
+        return dict(e=e, vir=vir, pres=pres, v=v)
+    o = hub.run(rank_main)[0]
+    s = synth.water_box(d=d)
+    e = eng.Engine(s, tc_groups=["System"], ref_t=[300.0], tau_t=[0.1], nsttcouple=10, nstcalcenergy=10, nstcomm=10, seed=7, **kw)
+    e.step(nst); e.synchronize()
+    er = e.energies(); virr, presr = e.virial()
+    _, vr, _ = e.get_state(); e.close()
+    terms = ("LJ", "COUL_SR", "COUL_RECIP", "COUL_EXCL", "KIN", "TEMP", "PRES", "POT")
+    return dict(dd={k: o["e"][k] for k in terms}, single={k: er[k] for k in terms},
+                vir_max_diff=float(np.abs(o["vir"] - virr).max()), vir_scale=float(np.abs(virr).max()),
+                pres_max_diff=float(np.abs(o["pres"] - presr).max()),
+                dv_rel_rms=float(np.sqrt(((o["v"] - vr) ** 2).mean() / (vr ** 2).mean())),
+                com_v=[float(c) for c in (s.mass[:, None] * o["v"]).sum(0) / s.mass.sum()])
+
+
 def main(world=2, steps=12, d=7.0):
     import faulthandler; faulthandler.dump_traceback_later(int(os.environ.get("MDX_DD_LIMIT", "150")), exit=True)
     import mdx
@@ -49,6 +78,7 @@ def main(world=2, steps=12, d=7.0):
         dx -= np.round(dx @ np.linalg.inv(s.box)) @ s.box
         res[label] = dict(dx_max=float(np.abs(dx).max()), dx_rms=float(np.sqrt((dx ** 2).mean())),
                           dv_rel_rms=float(np.sqrt(((o["v"] - vr) ** 2).mean() / (vr ** 2).mean())), partition=o["info"])
+    res["coupled"] = coupled(world, 21, d)
     print(json.dumps(res), flush=True)
 
 

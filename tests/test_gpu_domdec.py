@@ -31,6 +31,18 @@ def test_domains_match_single_handle(world, box):
     assert res["rest"]["dv_rel_rms"] < 2e-5, res
     # 12 steps with one renewal of the partition: 2.3e-7 nm RMS, the same as the one-domain path against the plain handle
     assert res["traj"]["dx_rms"] < 2e-6 and res["traj"]["dx_max"] < 5e-5, res
+    # Thermostat, centre-of-mass removal and energies across the domains (21 steps, coupling and energies every 10):
+    # the partial sums of the domains add up to the single handle's energies, virial and pressure, and the one
+    # V-rescale factor drawn from the summed kinetic energy leaves the same velocities.
+    c = res["coupled"]
+    scale = max(abs(c["single"][k]) for k in ("LJ", "COUL_SR", "COUL_RECIP", "COUL_EXCL"))
+    for k in ("LJ", "COUL_SR", "COUL_RECIP", "COUL_EXCL", "POT"):
+        assert abs(c["dd"][k] - c["single"][k]) < 2e-5 * scale, (k, c)
+    assert abs(c["dd"]["KIN"] - c["single"]["KIN"]) < 1e-4 * c["single"]["KIN"], c
+    assert abs(c["dd"]["TEMP"] - c["single"]["TEMP"]) < 0.05, c
+    assert c["vir_max_diff"] < 2e-4 * c["vir_scale"] and c["pres_max_diff"] < 3.0, c
+    assert c["dv_rel_rms"] < 1e-3, c
+    assert max(abs(v) for v in c["com_v"]) < 1e-5, c
 
 
 @pytest.mark.gpu
