@@ -390,8 +390,13 @@ __global__ void k_pcouple(DevState *dw, int kind, double tau_p, double ref_p, do
                             sqrt(2.0 * kT * compress * MDX_PRESFAC * dt_pc / (vol * tau_p)) * gauss;
         const double m = exp(deps / 3.0);
         mu[0] = mu[4] = mu[8] = m;
-        // work done by the scaling: -P0 dV (+ kinetic part through v scaling is handled by ekin)
-        dw->baro_integral -= 0.0;
+        // Energy the scaling puts into the system, taken out of the conserved quantity: positions scale by m, so the
+        // potential changes by -sum_i F_i . (m - 1) r_i = 2 (m - 1) tr(Xi) (Xi = -1/2 sum r x F, constraint part
+        // included); velocities scale by 1/m, so the kinetic energy changes by K (m^-2 - 1). To first order the sum is
+        // -P dV.
+        const double trvir = dw->vir[0] + dw->vir[4] + dw->vir[8];
+        const double ekin = dw->ekin_tensor[0] + dw->ekin_tensor[4] + dw->ekin_tensor[8];
+        dw->baro_integral -= 2.0 * (m - 1.0) * trvir + ekin * (1.0 / (m * m) - 1.0);
     } else if (kind == 2) {
         // Isotropic Parrinello-Rahman as GROMACS defines it [GMX-doc, "Parrinello-Rahman pressure coupling"]:
         // W^-1 = 4 pi^2 beta / (3 tau_p^2 L_max); the "force" on the box is t = b^-1T (P - P_ref) (the box rows are the

@@ -120,6 +120,24 @@ def test_crescale_scaling_matches_oracle(small_water):
         assert np.abs(box1 - mu * box0).max() < 1e-6
 
 
+def test_crescale_work_enters_the_conserved_quantity(small_water):
+    """No thermostat, C-rescale with a short time constant on a box that starts far from the reference pressure: the
+    barostat changes the volume by several per cent and the total energy with it; the conserved quantity (total energy
+    minus the energy put in by every scaling) must stay put where the total energy does not."""
+    s = small_water
+    e = eng.Engine(s, rc=1.0, dt=0.001, nstcalcenergy=5, pcoupl=1, tau_p=0.5, ref_p=2000.0, compressibility=4.5e-5, nstpcouple=5, seed=5)
+    e.step(401)
+    fr = e.pop_energy_frames()
+    e.close()
+    etot = fr[:, 2 + eng.E["POT"]] + fr[:, 2 + eng.E["KIN"]]
+    cons = fr[:, 2 + eng.E["CONSERVED"]]
+    vol = fr[:, 2 + eng.E["VOLUME"]]
+    assert abs(vol[-1] / vol[0] - 1.0) > 0.005           # the barostat did act
+    d_tot, d_cons = etot[-1] - etot[1], cons[-1] - cons[1]
+    assert abs(d_tot) > 20.0, d_tot
+    assert abs(d_cons) < 0.2 * abs(d_tot), (d_cons, d_tot)
+
+
 def test_parrinello_rahman_box_follows_oracle(small_complex):
     """The isotropic Parrinello-Rahman box ODE in a non-cubic (dodecahedral) cell: the oracle advances (box, box
     velocity) with the device's pressure tensor of each step; box and box velocity must agree all along."""
