@@ -4,9 +4,7 @@
 nvt_complex.mdp:10-11); the pipeline declares `PREFIX.log` and `PREFIX.edr` as rule outputs
 (/root/reference/Snakefile:218,258,299-300). The `.log` follows the familiar layout (step/time
 header, five right-aligned 15-column terms per row, closing `Performance:` line in ns/day and
-hour/ns). The `.edr` written here is a plain XDR stream of this package's own design (magic
--55556, term names and units, then one record of step, time and float64 values per frame); it
-is read back by `read_edr` and is not the enx layout of `gmx energy`.
+hour/ns). The `.edr` follows the enx layout of GROMACS energy files (see the comment at `EdrWriter`).
 """
 from __future__ import annotations
 
@@ -93,23 +91,44 @@ def performance_block(nsteps: int, dt_ps: float, wall_s: float) -> str:
             "                 (ns/day)    (hour/ns)\nPerformance: %12.3f %12.3f\n" % (wall_s, wall_s, nsday, hourns))
 
 
-EDR_MAGIC = -55556
+# ---------------------------------------------------------------------------------------------- .edr (enx layout)
+# The energy file of GROMACS ("enx", file version 5) as its source documents it (src/gromacs/fileio/enxio.cpp,
+# do_enxnms / do_eheader / do_enx), written the way a double-precision build writes it (a reader tells the precision
+# from the first real of a frame, -2e10, and `gmx energy` accepts either):
+#   file head   int -55555 | int version = 5 | int nre | nre x (XDR string name, XDR string unit)
+#   every frame real -2e10 | int -7777777 | int version | double t | int64 step | int nsum | int64 nsteps | double dt
+#               | int nre | int 0 | int nblock = 0 | int e_size | int 0 | int 0 | nre x real e
+#               (nsum = 0: no running sums, so a term is its value only; with nsum > 0 each term would be followed by
+#               its average and sum)
+# XDR: big endian, strings as a 4-byte length and the bytes padded to a multiple of four.
+# No GROMACS is installed where this was written: the layout follows the description above and is read back by
+# `read_edr`; it has not been opened by `gmx energy`.
+ENX_NAMES_MAGIC, ENX_FRAME_MAGIC, ENX_VERSION, ENX_FIRST_REAL = -55555, -7777777, 5, -2e10
+
+
+def _xdr_string(s: str) -> bytes:
+    b = s.encode()
+    return struct.pack(">i", len(b)) + b + b"\0" * (-len(b) % 4)
 
 
 class EdrWriter:
-    def __init__(self, path: str, append: bool = False):
+    def __init__(self, path: str, append: bool = False, dt_ps: float = 0.0):
         self.keys = [k for k, _, _ in TERMS]
+        self.dt = float(dt_ps)
+        self.last_step = None
         self.f = open(path, "ab" if append else "wb")
         if not append or self.f.tell() == 0:
-            self.f.write(struct.pack(">ii", EDR_MAGIC, len(TERMS)))
+            self.f.write(struct.pack(">iii", ENX_NAMES_MAGIC, ENX_VERSION, len(TERMS)))
             for _, name, unit in TERMS:
-                for s in (name, unit):
-                    b = s.encode()
-                    self.f.write(struct.pack(">i", len(b)) + b + b"\0" * (-len(b) % 4))
+                self.f.write(_xdr_string(name) + _xdr_string(unit))
 
     def frame(self, step, time, terms):
-        self.f.write(struct.pack(">qd", int(step), float(time)))
-        self.f.write(struct.pack(">%dd" % len(self.keys), *[float(terms.get(k, 0.0)) for k in self.keys]))
+        nre = len(self.keys)
+        nsteps = 1 if self.last_step is None else max(1, int(step) - self.last_step)
+        self.last_step = int(step)
+        self.f.write(struct.pack(">diidqiqdiiiiii", ENX_FIRST_REAL, ENX_FRAME_MAGIC, ENX_VERSION, float(time), int(step), 0, nsteps,
+                                 self.dt, nre, 0, 0, nre * 8 * 4, 0, 0))
+        self.f.write(struct.pack(">%dd" % nre, *[float(terms.get(k, 0.0)) for k in self.keys]))
 
     def flush(self):
         self.f.flush()
@@ -120,13 +139,15 @@ class EdrWriter:
 
 
 def read_edr(path: str):
-    """-> (names, units, list of (step, time, values))."""
+    """-> (names, units, list of (step, time, values)). Reads the enx layout in either precision (frames without blocks)."""
     with open(path, "rb") as f:
         data = f.read()
-    magic, n = struct.unpack_from(">ii", data, 0)
-    if magic != EDR_MAGIC:
-        raise ValueError(f"{path}: not an energy file written by this mdrun")
-    pos = 8
+    magic, version, n = struct.unpack_from(">iii", data, 0)
+    if magic != ENX_NAMES_MAGIC:
+        raise ValueError(f"{path}: not an energy file (the names block does not start with {ENX_NAMES_MAGIC})")
+    if version > ENX_VERSION:
+        raise ValueError(f"{path}: energy file version {version} is newer than {ENX_VERSION}")
+    pos = 12
     names, units = [], []
     for _ in range(n):
         for dst in (names, units):
@@ -135,10 +156,23 @@ def read_edr(path: str):
             dst.append(data[pos:pos + ln].decode())
             pos += ln + (-ln % 4)
     frames = []
-    rec = 16 + 8 * n
-    while pos + rec <= len(data):
-        step, t = struct.unpack_from(">qd", data, pos)
-        vals = struct.unpack_from(">%dd" % n, data, pos + 16)
-        frames.append((step, t, list(vals)))
-        pos += rec
+    while pos + 8 <= len(data):
+        if struct.unpack_from(">f", data, pos)[0] == struct.unpack(">f", struct.pack(">f", ENX_FIRST_REAL))[0]:
+            real, rsz = "f", 4
+        elif struct.unpack_from(">d", data, pos)[0] == ENX_FIRST_REAL:
+            real, rsz = "d", 8
+        else:
+            raise ValueError(f"{path}: frame at byte {pos} does not start with {ENX_FIRST_REAL}")
+        pos += rsz
+        fmagic, fver, t, step, nsum, nsteps, dt, nre, _, nblock = struct.unpack_from(">iidqiqdiii", data, pos)
+        if fmagic != ENX_FRAME_MAGIC:
+            raise ValueError(f"{path}: frame magic {fmagic} at byte {pos}")
+        pos += struct.calcsize(">iidqiqdiii")
+        if nblock != 0:
+            raise ValueError(f"{path}: frames with data blocks are not read here")
+        pos += 12                                   # e_size and two reserved ints
+        per = 3 if nsum > 0 else 1                  # value (+ average and sum when running sums are stored)
+        vals = struct.unpack_from(">%d%s" % (nre * per, real), data, pos)
+        pos += nre * per * rsz
+        frames.append((step, t, list(vals[::per])))
     return names, units, frames

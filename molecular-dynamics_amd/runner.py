@@ -622,7 +622,7 @@ def mdrun(argv, out=sys.stdout, err=sys.stderr) -> int:
             writer = FramePipeline(eng, nslots, xtc, trr, sel, dt, tinit, nthreads=2)
         if not appending:
             _backup(f_edr)
-        edr = enio.EdrWriter(f_edr, append=appending)
+        edr = enio.EdrWriter(f_edr, append=appending, dt_ps=dt)
         nst_e, nst_log = m.i("nstenergy"), m.i("nstlog")
 
         def due(n, s):
