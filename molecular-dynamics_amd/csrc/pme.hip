@@ -834,7 +834,9 @@ int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done)
         F.grid_in = s->grid; F.grid_out = s->phi; F.cgrid = s->cgrid; F.K0 = K0; F.K1 = K1; F.K2 = K2; F.K0c = K0 / 2 + 1;
         F.d = s->d; F.dw = s->d; F.bm0 = s->bmod[0]; F.bm1 = s->bmod[1]; F.bm2 = s->bmod[2]; F.beta = s->beta;
         auto lds = [](const FftArgs &f) { return sizeof(float2) * ((size_t)f.N + 2 * (size_t)f.nl * (f.N + 1)); };
-        const int nchunk = (F.K0c + 7) / 8;
+        static const int ynl0 = getenv("MDX_FFT_YNL") ? atoi(getenv("MDX_FFT_YNL")) : 8;
+        static const int xnl = getenv("MDX_FFT_XNL") ? atoi(getenv("MDX_FFT_XNL")) : 16;
+        const int nchunk = (F.K0c + ynl0 - 1) / ynl0;
         Fft2Args G;
         G.grid_in = s->grid; G.grid_out = s->phi; G.cgrid = s->cgrid; G.W0 = s->fftW[0]; G.W1 = s->fftW[1]; G.K0 = K0; G.K1 = K1; G.K0c = F.K0c;
         fft_split(K0, G.N01, G.N02); fft_split(K1, G.N11, G.N12);
@@ -847,24 +849,24 @@ int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done)
             hipLaunchKernelGGL(k_pme_fft2d<false>, dim3(K2), dim3(512), lds2, s->st_pme, G, (const DevState *)s->d);
         } else {
         // x forward
-        F.N = K0; fft_split(K0, F.N1, F.N2); F.W = s->fftW[0]; F.nl = 16;
+        F.N = K0; fft_split(K0, F.N1, F.N2); F.W = s->fftW[0]; F.nl = xnl;
         hipLaunchKernelGGL((k_pme_fft<0, false>), dim3((K1 * K2 + F.nl - 1) / F.nl), dim3(256), lds(F), s->st_pme, F);
         // y forward
-        F.N = K1; fft_split(K1, F.N1, F.N2); F.W = s->fftW[1]; F.nl = 8;
+        F.N = K1; fft_split(K1, F.N1, F.N2); F.W = s->fftW[1]; F.nl = ynl0;
         hipLaunchKernelGGL((k_pme_fft<1, false>), dim3(K2 * nchunk), dim3(256), lds(F), s->st_pme, F);
         }
         // z forward, influence function, z inverse
-        F.N = K2; fft_split(K2, F.N1, F.N2); F.W = s->fftW[2]; F.nl = 8;
+        F.N = K2; fft_split(K2, F.N1, F.N2); F.W = s->fftW[2]; F.nl = ynl0;
         if (energy) hipLaunchKernelGGL((k_pme_fft<2, true>), dim3(K1 * nchunk), dim3(256), lds(F), s->st_pme, F);
         else hipLaunchKernelGGL((k_pme_fft<2, false>), dim3(K1 * nchunk), dim3(256), lds(F), s->st_pme, F);
         if (planes) {
             hipLaunchKernelGGL(k_pme_fft2d<true>, dim3(K2), dim3(512), lds2, s->st_pme, G, (const DevState *)s->d);
         } else {
         // y inverse
-        F.N = K1; fft_split(K1, F.N1, F.N2); F.W = s->fftW[1]; F.nl = 8;
+        F.N = K1; fft_split(K1, F.N1, F.N2); F.W = s->fftW[1]; F.nl = ynl0;
         hipLaunchKernelGGL((k_pme_fft<3, false>), dim3(K2 * nchunk), dim3(256), lds(F), s->st_pme, F);
         // x inverse
-        F.N = K0; fft_split(K0, F.N1, F.N2); F.W = s->fftW[0]; F.nl = 16;
+        F.N = K0; fft_split(K0, F.N1, F.N2); F.W = s->fftW[0]; F.nl = xnl;
         hipLaunchKernelGGL((k_pme_fft<4, false>), dim3((K1 * K2 + F.nl - 1) / F.nl), dim3(256), lds(F), s->st_pme, F);
         }
         s->grid_clean = true;
