@@ -75,7 +75,7 @@ struct MdxStamp {
     long long *mx;
     // first workgroup stamps the start, the last one (by index: about the last to be dispatched) the end; plain
     // stores, because thousands of workgroups updating one address would themselves stretch the kernel
-    // (all_end: every workgroup stamps the end with an atomic maximum, for a kernel whose last workgroups may be idle)
+    // (all_end: every workgroup stamps the end, for a kernel whose last workgroups may be idle)
     bool amax;
     __device__ MdxStamp(const DevState *d, int id, bool all_end = false) {
         DevState *w = const_cast<DevState *>(d);
@@ -85,7 +85,9 @@ struct MdxStamp {
     }
     __device__ ~MdxStamp() {
         if (!mx) return;
-        if (amax) atomicMax((unsigned long long *)mx, (unsigned long long)wall_clock64()); else *mx = (long long)wall_clock64();
+        // (all_end: every workgroup stores its end time, the last store to arrive stands; an atomic maximum on one address
+        // from every workgroup stretched the kernel it was meant to time by tens of microseconds)
+        *mx = (long long)wall_clock64();
     }
 };
 #define MDX_STAMP(d, id) MdxStamp stamp_((d), (id))

@@ -172,6 +172,7 @@ struct SpreadChunkArgs {
     int K0, K1, K2;
     int T0, T1, PPC;                    // window size in x, y and planes
     int sc_per_chunk;                   // super-clusters per workgroup (<= 4)
+    int abl;                            // timing experiments (MDX_SPREAD_ABL): 1 no flush atomics, 2 no LDS atomics
     float delta;
     float *grid;
     const float4 *v_home;
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(256) void k_pme_spread_chunk(SpreadChunkArgs A, con
                     for (int b = 0; b < 4; b++) {
                         const float qzy = qz * wys[b];
 #pragma unroll
-                        for (int a = 0; a < 4; a++) atomicAdd(&t[b * A.T0 + a], __float2int_rn(qzy * wxs[a]));
+                        for (int a = 0; a < 4; a++) if (!(A.abl & 2)) atomicAdd(&t[b * A.T0 + a], __float2int_rn(qzy * wxs[a]));
                     }
                 } else {
                     // outside the window (an atom that drifted far, or a chunk taller than the window): straight to the grid
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256) void k_pme_spread_chunk(SpreadChunkArgs A, con
             if (vi != 0) {
                 int gx = oxw[pl] + rx, gy = oyw[pl] + ry;
                 gx -= gx >= A.K0 ? A.K0 : 0; gy -= gy >= A.K1 ? A.K1 : 0;
-                atomicAdd(&A.grid[((size_t)gz * A.K1 + gy) * A.K0 + gx], (float)vi * (1.0f / MDX_SPREAD_SCALE));
+                if (!(A.abl & 1)) atomicAdd(&A.grid[((size_t)gz * A.K1 + gy) * A.K0 + gx], (float)vi * (1.0f / MDX_SPREAD_SCALE));
             }
             gz++; gz -= gz >= A.K2 ? A.K2 : 0;
         }
@@ -778,6 +779,8 @@ int mdx_launch_pme_spread(mdx_system *s, hipStream_t st, bool signal)
             C.ncx = s->ncx; C.ncy = s->ncy; C.col_scstart = s->col_scstart; C.x = s->x; C.perm = s->perm; C.perm_src = s->perm_src;
             C.shift_s = s->shift_s; C.sbb_lo = s->sbb_lo; C.sbb_hi = s->sbb_hi; C.K0 = K0; C.K1 = K1; C.K2 = K2; C.T0 = A.T0; C.T1 = A.T1;
             C.sc_per_chunk = 4;
+            static const int spread_abl = getenv("MDX_SPREAD_ABL") ? atoi(getenv("MDX_SPREAD_ABL")) : 0;
+            C.abl = spread_abl & 3;
             // planes a chunk of four super-clusters reaches: their height (a super-cluster of 64 atoms is about as tall
             // as a column is wide; taller ones in thin regions fall back to the grid) plus the spline support and the margin
             const double sc_h = std::cbrt(64.0 * (bxd[0] * bxd[4] * bxd[8]) / std::max(1, s->n));
