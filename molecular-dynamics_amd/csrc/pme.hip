@@ -48,6 +48,15 @@ __device__ __forceinline__ void grid_coords(const DevBox &b, float4 p, int K0, i
     u[2] = K2 * (p.z * b.inv[8]);
 }
 __device__ __forceinline__ int pmod(int a, int K) { a %= K; return a < 0 ? a + K : a; }
+// The same for |a| < 2^22 through a float reciprocal and one correction step either way: a handful of instructions and
+// two temporaries where the integer division takes a few dozen of each.
+__device__ __forceinline__ int pmod_small(int a, int K, float invK)
+{
+    int r = a - (int)floorf((float)a * invK) * K;
+    r += r < 0 ? K : 0;
+    r -= r >= K ? K : 0;
+    return r;
+}
 
 #define MDX_SPREAD_SCALE 67108864.0f      // 2^26
 
@@ -267,6 +276,150 @@ __global__ __launch_bounds__(256) void k_pme_spread_chunk(SpreadChunkArgs A, con
         int gz = gz0;
 #pragma unroll 1
         for (int pl = 0; pl < A.PPC; pl++) {
+            const int vi = ((const int *)tile)[pl * t01 + i];
+            if (vi != 0) {
+                int gx = oxw[pl] + rx, gy = oyw[pl] + ry;
+                gx -= gx >= A.K0 ? A.K0 : 0; gy -= gy >= A.K1 ? A.K1 : 0;
+                if (!(A.abl & 1)) atomicAdd(&A.grid[((size_t)gz * A.K1 + gy) * A.K0 + gx], (float)vi * (1.0f / MDX_SPREAD_SCALE));
+            }
+            gz++; gz -= gz >= A.K2 ? A.K2 : 0;
+        }
+    }
+}
+
+// Charge spreading over slabs of grid planes. A workgroup owns the planes [tlo, tlo + SP) (unwrapped plane numbers; the
+// flush wraps them) above a block of qx x qy neighbouring search columns: it collects the super-clusters of those
+// columns that can reach its planes, evaluates each of their atoms once (one thread per atom, a wave per super-cluster)
+// and adds the contributions that fall on its planes to an LDS window with integer atomics (fixed point, 2^-26 e). The
+// windows of different slabs share no grid point and those of neighbouring column blocks overlap by the spline
+// support only, so the flush issues fewer float atomics than one window per column does (1.6 instead of 2.3 per grid
+// point with 2 x 2 columns), and those atomics are what the kernel's time goes into. An atom is visited by every slab
+// its four planes touch ((SP + 3) / SP times on average).
+struct SpreadSlabArgs {
+    int ncx, ncy, qx, qy;               // search columns; columns per workgroup in x and y
+    const int *col_scstart;
+    const float4 *x;
+    const int *perm, *perm_src, *shift_s;
+    const float4 *sbb_lo, *sbb_hi;      // super-cluster bounding boxes of the last search (brick coordinates)
+    int K0, K1, K2;
+    int T0, T1, SP;                     // window size in x and y; planes per slab
+    int tlo0;                           // lowest unwrapped plane of the first slab
+    int abl;                            // timing experiments (MDX_SPREAD_ABL): 1 no flush atomics, 2 no LDS atomics
+    float delta;
+    float *grid;
+    const float4 *v_home;
+};
+#define MDX_SPREAD_MAXSC 256            // candidate super-clusters of one workgroup (qx qy columns of at most 32 each)
+
+__global__ __launch_bounds__(256) void k_pme_spread_slab(SpreadSlabArgs A, const DevState *__restrict__ d)
+{
+    MDX_STAMP_ALL(d, 3);
+    extern __shared__ float tile[];
+    int *ox = (int *)(tile + A.SP * A.T1 * A.T0);
+    int *oy = ox + A.SP, *oxw = oy + A.SP, *oyw = oxw + A.SP;         // window origins per plane: as computed, and wrapped into the grid
+    __shared__ int s_list[MDX_SPREAD_MAXSC];
+    __shared__ int s_n;
+    const int nqx = (A.ncx + A.qx - 1) / A.qx;
+    const int cx0 = (blockIdx.x % nqx) * A.qx, cy0 = (blockIdx.x / nqx) * A.qy;
+    const int ncolx = min(A.qx, A.ncx - cx0), ncoly = min(A.qy, A.ncy - cy0);
+    const int tlo = A.tlo0 + blockIdx.y * A.SP;
+    const DevBox &bx = d->box;
+    const float wx = bx.h[0] / A.ncx, wy = bx.h[4] / A.ncy;
+    const float x_lo = cx0 * wx - A.delta, x_hi = (cx0 + ncolx) * wx + A.delta;
+    const float y_lo = cy0 * wy - A.delta, y_hi = (cy0 + ncoly) * wy + A.delta;
+    const float kz = A.K2 * bx.inv[8];
+    if (threadIdx.x == 0) s_n = 0;
+    for (int p = threadIdx.x; p < A.SP; p += blockDim.x) {
+        // atoms that touch plane t have floor(u_z) in [t - 3, t]: their z range, and from it the lowest u_x, u_y inside the block
+        const int t = tlo + p;
+        const float z_lo = (t - 3) / kz - A.delta, z_hi = (t + 1) / kz + A.delta;
+        const float ux = A.K0 * (x_lo * bx.inv[0] + fminf(y_lo * bx.inv[3], y_hi * bx.inv[3]) + fminf(z_lo * bx.inv[6], z_hi * bx.inv[6]));
+        const float uy = A.K1 * (y_lo * bx.inv[4] + fminf(z_lo * bx.inv[7], z_hi * bx.inv[7]));
+        ox[p] = (int)floorf(ux); oy[p] = (int)floorf(uy);
+        oxw[p] = pmod(ox[p], A.K0); oyw[p] = pmod(oy[p], A.K1);
+    }
+    const int nt = A.SP * A.T1 * A.T0;
+#pragma unroll 1
+    for (int k = threadIdx.x; k < nt; k += blockDim.x) tile[k] = 0.0f;
+    __syncthreads();
+    // super-clusters of the block's columns whose atoms can reach the slab
+    for (int cy = cy0; cy < cy0 + ncoly; cy++)
+        for (int cx = cx0; cx < cx0 + ncolx; cx++) {
+            const int col = cy * A.ncx + cx;
+            const int s0 = A.col_scstart[col], s1 = A.col_scstart[col + 1];
+            for (int sc = s0 + (int)threadIdx.x; sc < s1; sc += blockDim.x) {
+                const int plo = (int)floorf(kz * (A.sbb_lo[sc].z - A.delta)), phi = (int)floorf(kz * (A.sbb_hi[sc].z + A.delta)) + 3;
+                if (phi >= tlo && plo < tlo + A.SP) {
+                    const int k = atomicAdd(&s_n, 1);
+                    if (k < MDX_SPREAD_MAXSC) s_list[k] = sc;
+                }
+            }
+        }
+    __syncthreads();
+    const int nsc = min(s_n, MDX_SPREAD_MAXSC);
+    const int lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int k = threadIdx.x >> 6; k < nsc; k += 4) {
+        const int gs = s_list[k] * 64 + lane;
+        if (A.perm[gs] >= 0) {
+            const int src = A.perm_src[gs];
+            float4 p = A.x[src];
+            const bool skip = p.w == 0.0f || (A.v_home && A.v_home[src].w == 0.0f);
+            if (!skip) {
+                int sa, sb, sc;
+                unpack_shift(A.shift_s[gs], sa, sb, sc);
+                p.x += sa * bx.h[0] + sb * bx.h[3] + sc * bx.h[6];
+                p.y += sb * bx.h[4] + sc * bx.h[7];
+                p.z += sc * bx.h[8];
+                float u[3];
+                grid_coords(bx, p, A.K0, A.K1, A.K2, u);
+                const int px = (int)floorf(u[0]), py = (int)floorf(u[1]), pz = (int)floorf(u[2]);
+                float wxs[4], wys[4], wzs[4], dws[4];
+                bspline4(u[0] - px, wxs, dws); bspline4(u[1] - py, wys, dws); bspline4(u[2] - pz, wzs, dws);
+                const float qs = p.w * MDX_SPREAD_SCALE;
+                // (at most 40 registers, so that three of these waves fit on a SIMD beside three 128-register nonbonded waves)
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int pl = pz + c - tlo;
+                    if (pl >= 0 && pl < A.SP) {             // this plane of the atom belongs to the slab
+                        const float qz = qs * wzs[c];
+                        const int rx0 = px - ox[pl], ry0 = py - oy[pl];
+                        if (rx0 >= 0 && rx0 + 3 < A.T0 && ry0 >= 0 && ry0 + 3 < A.T1) {
+                            int *t = (int *)tile + (pl * A.T1 + ry0) * A.T0 + rx0;
+#pragma unroll
+                            for (int b = 0; b < 4; b++) {
+                                const float qzy = qz * wys[b];
+#pragma unroll
+                                for (int a = 0; a < 4; a++) if (!(A.abl & 2)) atomicAdd(&t[b * A.T0 + a], __float2int_rn(qzy * wxs[a]));
+                            }
+                        } else {
+                            // outside the window (an atom that drifted far): straight to the grid
+                            const int gz = pmod_small(pz + c, A.K2, 1.0f / A.K2);
+                            const float qzf = p.w * wzs[c];
+#pragma unroll 1
+                            for (int ba = 0; ba < 16; ba++) {       // rare path: rolled, registers matter more than speed here
+                                const int b = ba >> 2, a = ba & 3;
+                                const float wyb = (b == 0) ? wys[0] : ((b == 1) ? wys[1] : ((b == 2) ? wys[2] : wys[3]));
+                                const float wxa = (a == 0) ? wxs[0] : ((a == 1) ? wxs[1] : ((a == 2) ? wxs[2] : wxs[3]));
+                                const int gy = pmod_small(py + b, A.K1, 1.0f / A.K1), gx = pmod_small(px + a, A.K0, 1.0f / A.K0);
+                                atomicAdd(&A.grid[((size_t)gz * A.K1 + gy) * A.K0 + gx], qzf * wyb * wxa);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // Flush of the non-zero window points: a thread keeps its (rx, ry) inside the plane window and walks the planes
+    const int t01 = A.T0 * A.T1;
+    const int gz0 = pmod(tlo, A.K2);
+#pragma unroll 1
+    for (int i = threadIdx.x; i < t01; i += blockDim.x) {
+        const int ry = i / A.T0, rx = i - ry * A.T0;
+        int gz = gz0;
+#pragma unroll 1
+        for (int pl = 0; pl < A.SP; pl++) {
             const int vi = ((const int *)tile)[pl * t01 + i];
             if (vi != 0) {
                 int gx = oxw[pl] + rx, gy = oyw[pl] + ry;
@@ -774,12 +927,34 @@ int mdx_launch_pme_spread(mdx_system *s, hipStream_t st, bool signal)
         A.delta = (float)delta; A.grid = s->grid; A.v_home = s->dd_on ? s->v : nullptr;
         if (getenv("MDX_PME_NOTILE")) { A.T0 = 4; A.T1 = 4; }
         static const bool use_col = getenv("MDX_SPREAD") && !strcmp(getenv("MDX_SPREAD"), "col");
-        if (!use_col) {
+        static const bool use_chunk = getenv("MDX_SPREAD") && !strcmp(getenv("MDX_SPREAD"), "chunk");
+        static const int spread_abl = getenv("MDX_SPREAD_ABL") ? atoi(getenv("MDX_SPREAD_ABL")) : 0;
+        if (!use_col && !use_chunk) {
+            static const int qx = getenv("MDX_SPREAD_QX") ? atoi(getenv("MDX_SPREAD_QX")) : 2;
+            static const int qy = getenv("MDX_SPREAD_QY") ? atoi(getenv("MDX_SPREAD_QY")) : 2;
+            static const int sp = getenv("MDX_SPREAD_SP") ? atoi(getenv("MDX_SPREAD_SP")) : 8;
+            SpreadSlabArgs B;
+            B.ncx = s->ncx; B.ncy = s->ncy; B.qx = std::max(1, qx); B.qy = std::max(1, qy);
+            while (B.qx * B.qy * (MDX_MAX_COL / 64) > MDX_SPREAD_MAXSC) { if (B.qx >= B.qy) B.qx--; else B.qy--; }
+            B.col_scstart = s->col_scstart; B.x = s->x; B.perm = s->perm; B.perm_src = s->perm_src; B.shift_s = s->shift_s;
+            B.sbb_lo = s->sbb_lo; B.sbb_hi = s->sbb_hi; B.K0 = K0; B.K1 = K1; B.K2 = K2; B.SP = std::max(2, sp);
+            const double wxq = B.qx * bxd[0] / s->ncx + 2 * delta, wyq = B.qy * bxd[4] / s->ncy + 2 * delta;
+            B.T0 = std::min(K0, (int)ceil(K0 * (inv0 * wxq + fabs(inv3) * wyq + fabs(inv6) * wz)) + 5);
+            B.T1 = std::min(K1, (int)ceil(K1 * (inv4 * wyq + fabs(inv7) * wz)) + 5);
+            while ((size_t)B.SP * B.T0 * B.T1 * 4 > 60 * 1024 && B.SP > 2) B.SP--;
+            // Unwrapped planes an atom of the brick can touch: -1 .. K2 + 3 with a drift of less than a plane (the
+            // margin of 0.12 nm); the slabs cover -4 .. K2 + 7 at least, three planes (0.47 nm) more on either side.
+            B.tlo0 = -4;
+            const int nslab = (K2 + 12 + B.SP - 1) / B.SP;
+            B.abl = spread_abl & 3; B.delta = (float)delta; B.grid = s->grid; B.v_home = s->dd_on ? s->v : nullptr;
+            const size_t ldss = (size_t)B.SP * B.T0 * B.T1 * 4 + (size_t)B.SP * 16;
+            const int nq = ((s->ncx + B.qx - 1) / B.qx) * ((s->ncy + B.qy - 1) / B.qy);
+            hipLaunchKernelGGL(k_pme_spread_slab, dim3(nq, nslab), dim3(256), ldss, st, B, (const DevState *)s->d);
+        } else if (!use_col) {
             SpreadChunkArgs C;
             C.ncx = s->ncx; C.ncy = s->ncy; C.col_scstart = s->col_scstart; C.x = s->x; C.perm = s->perm; C.perm_src = s->perm_src;
             C.shift_s = s->shift_s; C.sbb_lo = s->sbb_lo; C.sbb_hi = s->sbb_hi; C.K0 = K0; C.K1 = K1; C.K2 = K2; C.T0 = A.T0; C.T1 = A.T1;
             C.sc_per_chunk = 4;
-            static const int spread_abl = getenv("MDX_SPREAD_ABL") ? atoi(getenv("MDX_SPREAD_ABL")) : 0;
             C.abl = spread_abl & 3;
             // planes a chunk of four super-clusters reaches: their height (a super-cluster of 64 atoms is about as tall
             // as a column is wide; taller ones in thin regions fall back to the grid) plus the spline support and the margin
