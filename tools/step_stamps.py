@@ -20,7 +20,12 @@ for kv in filter(None, os.environ.get("MDX_DEBUG_LATE", "").split(",")):      # 
 def stamped(nlead, nstamp, ntrail):
     """nlead steps, reset, nstamp stamped steps, ntrail more steps, all enqueued back to back"""
     e.synchronize()
-    e.step(nlead); e.debug_stamps(reset=True); e.step(nstamp); 
+    if nlead > 0:
+        # two steps in one call: the stamps are plain stores, so they show the second step, whose side streams were
+        # released by its predecessor in the same call (as in a long run)
+        e.step(nlead - 1); e.debug_stamps(reset=True); e.step(nstamp + 1)
+    else:
+        e.debug_stamps(reset=True); e.step(nstamp)
     t = e.debug_stamps()
     return t
 # align to the step counter: plain steps are those with step % 10 not in (0, 9) and no list rebuild
