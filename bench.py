@@ -177,7 +177,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="diagnostic with --no-output: steps per mdx_step call")
     ap.add_argument("--ring", type=int, default=8, help="pinned trajectory-frame slots between the GPU and the encoder threads")
     ap.add_argument("--encoders", type=int, default=2, help="frames compressed at the same time (host threads)")
-    ap.add_argument("--encoder-threads", type=int, default=4, help="threads that share the compression of one frame (segments)")
+    ap.add_argument("--encoder-threads", type=int, default=8,
+                    help="threads that share the compression of one frame (segments): 8 keep the drain of the last frame, which a short "
+                         "timed window sees in full, at 0.4 ms; the steady state needs two cores per rank")
     ap.add_argument("--prime-steps", type=int, default=40,
                     help="un-timed steps before the warmup that run every kernel variant, one pair search, the coupling steps and the "
                          "frame pipeline once (first launches and first frames carry one-off costs of milliseconds)")
