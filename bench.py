@@ -177,9 +177,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="diagnostic with --no-output: steps per mdx_step call")
     ap.add_argument("--ring", type=int, default=8, help="pinned trajectory-frame slots between the GPU and the encoder threads")
     ap.add_argument("--encoders", type=int, default=2, help="frames compressed at the same time (host threads)")
-    ap.add_argument("--encoder-threads", type=int, default=8,
-                    help="threads that share the compression of one frame (segments): 8 keep the drain of the last frame, which a short "
-                         "timed window sees in full, at 0.4 ms; the steady state needs two cores per rank")
+    ap.add_argument("--encoder-threads", type=int, default=0,
+                    help="threads that share the compression of one frame (segments); 0: 8 for one rank (they keep the drain of the "
+                         "last frame, which a short timed window sees in full, at 0.4 ms), 4 per rank when several ranks share the host")
     ap.add_argument("--prime-steps", type=int, default=40,
                     help="un-timed steps before the warmup that run every kernel variant, one pair search, the coupling steps and the "
                          "frame pipeline once (first launches and first frames carry one-off costs of milliseconds)")
@@ -196,6 +196,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local)
+    if args.encoder_threads <= 0:
+        args.encoder_threads = 8 if world == 1 else 4
     use_dist = world > 1 or bool(os.environ.get("MDX_BENCH_FORCE_DIST"))     # the latter: rehearsal of the N>1 code path on one GPU
     if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
