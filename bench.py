@@ -390,7 +390,7 @@ def main():
         try:
             K = e.grid; k3 = 4.0 * K[0] * K[1] * K[2]; n = s.natoms; nw = len(s.settles)
             sec = []
-            for stage, name, nbytes in ((6, "k_pme_spread_chunk", 16.0 * n + 2 * k3), (7, "k_pme_gather", k3 + 28.0 * n),
+            for stage, name, nbytes in ((6, "k_pme_spread_slab", 16.0 * n + 2 * k3), (7, "k_pme_gather", k3 + 28.0 * n),
                                         (4, "k_leapfrog + k_settle + k_lincs", 64.0 * n + 144.0 * nw), (5, "k_prepare", 16.0 * n + 28.0 * n)):
                 ms = e.debug_time_stage(stage, 50)
                 gbs = nbytes / (ms * 1e-3) / 1e9
