@@ -270,6 +270,12 @@ int mdx_dd_scalars(mdx_system *sys, void **ekinh_dev, void **com_dev);
 int mdx_dd_tcouple(mdx_system *sys, int before_first_step);
 int mdx_dd_kinetic(mdx_system *sys);
 int mdx_dd_com(mdx_system *sys, int phase);
+/* Pressure coupling of a decomposed run (C-rescale, `pcoupl`/`tau_p`/`ref_p`/`compressibility` of
+ * /root/reference/mdp/production.mdp:36-40 with the barostat BASELINE.json names): a coupling step leaves the domain's
+ * share of the pressure tensor at `pres_dev` (9 doubles); the caller sums it over the domains and calls mdx_dd_pcouple,
+ * which scales box, atoms and velocities by the factor every domain draws alike and returns the new box. */
+int mdx_dd_pressure(mdx_system *sys, void **pres_dev);
+int mdx_dd_pcouple(mdx_system *sys, double *box9);
 /* Time the nonbonded kernel with HIP events on the handle's stream (bench only): on = n > 0 samples every n-th
  * force-only launch (a stride such as 7 does not lock onto the 10- and 20-step cadences of energy and search steps). */
 int mdx_enable_kernel_timing(mdx_system *sys, int on);

@@ -919,7 +919,8 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early)
             frame_steps(s).push_back(step);
         }
     }
-    if (do_pc) if ((rc = mdx_launch_pcouple(s))) return rc;
+    // (a domain of a decomposed run leaves the scaling to the caller, who sums the pressure over the domains first: mdx_dd_pcouple)
+    if (do_pc && !s->dd_on) if ((rc = mdx_launch_pcouple(s))) return rc;
     if (s->ntc > 0 && ((step + 1) % s->nsttcouple == 0)) {
         if (!need_vir) {
             if ((rc = mdx_launch_clear(s, false, true, false))) return rc;

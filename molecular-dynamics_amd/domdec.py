@@ -284,10 +284,13 @@ class DecomposedWater:
     def __init__(self, sysm: MDSystem, device: int = 0, rc: float = 1.0, dt: float = 0.002, nstlist: int = 20,
                  ref_t: float | None = 300.0, tau_t: float = 0.1, nsttcouple: int = 10, fourierspacing: float = 0.16,
                  rlist: float | None = None, seed: int = 1, group=None, dims=None, nstcalcenergy: int = 0,
-                 transport=None, global_coupling: bool = True, nstcomm: int = 0):
+                 transport=None, global_coupling: bool = True, nstcomm: int = 0, pcoupl: str | None = None, tau_p: float = 2.0,
+                 ref_p: float = 1.0, compressibility: float = 4.5e-5, nstpcouple: int = 10):
         """global_coupling: one V-rescale factor for the whole system from the kinetic energy summed over the domains
         (every domain draws it from the same random stream); False: every domain is its own thermostat group.
-        nstcomm > 0: centre-of-mass motion of the whole system removed every nstcomm steps."""
+        nstcomm > 0: centre-of-mass motion of the whole system removed every nstcomm steps.
+        pcoupl = "c-rescale": isotropic stochastic cell rescaling from the pressure summed over the domains, every nstpcouple
+        steps (needs the shared thermostat seed: every domain draws the same factor)."""
         from . import engine as eng
         self.tr = transport if transport is not None else Transport(group)
         self.rank, self.world = self.tr.rank, self.tr.world
@@ -316,10 +319,20 @@ class DecomposedWater:
         self.cap = min(self.home_cap + self.halo_cap, self.nmol + 256)
         tmpl = _template(self.cap, self.box_np)
         grid = U.pme_grid(self.box_np, fourierspacing)
+        if pcoupl not in (None, "no", "c-rescale"):
+            raise ValueError("the decomposed path couples the pressure with c-rescale only")
+        self.pcoupl = pcoupl == "c-rescale"
+        if self.pcoupl and not global_coupling:
+            raise ValueError("pressure coupling across domains needs global_coupling (one random stream for all domains)")
+        self.nstpcouple = int(nstpcouple)
+        self.rlist_margin = self.rlist + 2 * MOL_RADIUS + 0.02
         self.engine = eng.Engine(tmpl, rc=rc, rlist=self.rlist, dt=dt, nstlist=nstlist, pme=True, grid=grid, device=device,
                                  tc_groups=["System"] if ref_t is not None else None, ref_t=[ref_t or 300.0], tau_t=[tau_t],
                                  nsttcouple=nsttcouple, nstcalcenergy=nstcalcenergy, nstcomm=0,
-                                 seed=seed if global_coupling else seed + self.rank)
+                                 pcoupl=1 if self.pcoupl else 0, tau_p=tau_p, ref_p=ref_p, compressibility=compressibility,
+                                 nstpcouple=nstpcouple, seed=seed if global_coupling else seed + self.rank)
+        if self.pcoupl:
+            self.pres_t = torch.as_tensor(_DevArray(self.engine.dd_pressure(), (9,), "<f8"), device=self.dev)
         self.thermostat = ref_t is not None
         self.global_coupling = bool(global_coupling)
         self.nsttcouple, self.nstcomm, self.nstcalcenergy = int(nsttcouple), int(nstcomm), int(nstcalcenergy)
@@ -400,6 +413,9 @@ class DecomposedWater:
         return recs[:, :9].reshape(-1, 3, 3), recs[:, 9:].reshape(-1, 3, 3), idss
 
     def repartition(self):
+        if self.pcoupl:
+            # the cell has been rescaled since the last partition: halo margins in fractional coordinates follow it
+            self.margins = fractional_margins(self.box, self.rlist_margin)
         x_all, v_all, ids_all = self._gather_all()
         own = owner_of(fractional(x_all[:, 0, :].double(), self.box), self.dims)
         self._install(x_all, v_all, ids_all, own)
@@ -464,6 +480,19 @@ class DecomposedWater:
             with self._exclusive():
                 say("end"); self.engine.dd_step_end()
             done = self.nsteps_done + 1
+            if self.pcoupl and self.nsteps_done % self.nstpcouple == 0:
+                # the step left this domain's share of the pressure in the scalars: sum it, scale every domain alike, and
+                # put the share back (energies() adds the shares up itself)
+                self.engine.dd_stream_sync()
+                share = self.pres_t.clone()
+                self.tr.all_reduce_sum_(self.pres_t); torch.cuda.synchronize(self.dev)
+                with self._exclusive():
+                    box = self.engine.dd_pcouple()
+                self.pres_t.copy_(share); torch.cuda.synchronize(self.dev)
+                self.box_np = np.asarray(box, dtype=np.float64)
+                self.box = torch.tensor(self.box_np, dtype=torch.float64, device=self.dev)
+                self.volume = float(abs(np.linalg.det(self.box_np)))
+                self.density = 3 * self.nmol / self.volume
             if shared_tc and done % self.nsttcouple == 0:
                 # the step left the home atoms' half-step kinetic energy in the scalars: sum, then one factor for all
                 self.engine.dd_stream_sync()

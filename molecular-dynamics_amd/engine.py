@@ -34,7 +34,7 @@ SYMBOLS = [
     "mdx_synchronize", "mdx_get_list_stats", "mdx_pop_energy_frames", "mdx_pop_pull_records",
     "mdx_enable_kernel_timing", "mdx_get_kernel_timing", "mdx_debug_time_nonbonded", "mdx_debug_set", "mdx_debug_wave_times", "mdx_debug_stamps",
     "mdx_dd_load", "mdx_dd_pack", "mdx_dd_unpack", "mdx_dd_step_begin", "mdx_dd_wait_spread", "mdx_dd_step_end", "mdx_dd_grid",
-    "mdx_dd_stream_sync", "mdx_dd_state_pointers", "mdx_dd_set_roles", "mdx_dd_scalars", "mdx_dd_tcouple", "mdx_dd_kinetic", "mdx_dd_com",
+    "mdx_dd_stream_sync", "mdx_dd_state_pointers", "mdx_dd_set_roles", "mdx_dd_scalars", "mdx_dd_tcouple", "mdx_dd_kinetic", "mdx_dd_com", "mdx_dd_pressure", "mdx_dd_pcouple",
     "mdx_debug_time_stage", "mdx_set_step", "mdx_generate_velocities", "mdx_constrain_start", "mdx_minimize",
     "mdx_frame_ring", "mdx_capture_frame", "mdx_frame_wait",
 ]
@@ -135,6 +135,7 @@ def load_library(path: str | None = None):
     L.mdx_dd_set_roles.argtypes = [vp, c_int, c_int]
     L.mdx_dd_scalars.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
     L.mdx_dd_tcouple.argtypes = [vp, c_int]; L.mdx_dd_kinetic.argtypes = [vp]; L.mdx_dd_com.argtypes = [vp, c_int]
+    L.mdx_dd_pressure.argtypes = [vp, ctypes.POINTER(ctypes.c_void_p)]; L.mdx_dd_pcouple.argtypes = [vp, ctypes.POINTER(c_d)]
     L.mdx_debug_stamps.argtypes = [vp, c_int, ctypes.POINTER(ctypes.c_longlong)]
     L.mdx_debug_time_stage.argtypes = [vp, c_int, c_int, dp]
     L.mdx_set_step.argtypes = [vp, ctypes.c_longlong]
@@ -596,6 +597,18 @@ class Engine:
 
     def dd_kinetic(self):
         self._call("mdx_dd_kinetic")
+
+    def dd_pressure(self):
+        """Device pointer of the domain's share of the pressure tensor (9 doubles) after a coupling step."""
+        a = ctypes.c_void_p(0)
+        self._call("mdx_dd_pressure", ctypes.byref(a))
+        return a.value
+
+    def dd_pcouple(self):
+        """Scale by the C-rescale factor drawn from the (summed) pressure in the scalars; returns the new box (3, 3)."""
+        b = np.zeros(9, np.float64)
+        self._call("mdx_dd_pcouple", _p(b, ctypes.c_double))
+        return b.reshape(3, 3)
 
     def dd_com(self, phase):
         self._call("mdx_dd_com", int(phase))

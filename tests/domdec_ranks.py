@@ -61,6 +61,40 @@ def coupled(world, nst, d):
                 com_v=[float(c) for c in (s.mass[:, None] * o["v"]).sum(0) / s.mass.sum()])
 
 
+def coupled_npt(world, nst, d):
+    """C-rescale pressure coupling across the domains against the single handle: same seed, so the same stochastic
+    scaling factors as long as the summed pressure agrees; the cell after `nst` steps (three coupling steps) and the
+    positions are compared."""
+    import mdx
+    from mdx import synth, domdec, engine as eng
+    hub = domdec.ThreadTransport.Hub(world)
+    kw = dict(rc=1.0, dt=0.002, nstlist=10, rlist=1.1)
+    pk = dict(tau_p=1.0, ref_p=1.0, compressibility=4.5e-5, nstpcouple=10)
+
+    def rank_main(rank, transport):
+        dd = domdec.DecomposedWater(synth.water_box(d=d), device=0, ref_t=300.0, tau_t=0.1, nsttcouple=10, nstcalcenergy=10,
+                                    seed=11, transport=transport, pcoupl="c-rescale", **pk, **kw)
+        dd.step(nst); dd.synchronize()
+        e, vir, pres = dd.energies()
+        x, v = dd.gather_state()
+        box = dd.box_np.copy()
+        dd.close()
+        return dict(e=e, pres=pres, x=x, box=box)
+    o = hub.run(rank_main)[0]
+    s = synth.water_box(d=d)
+    e = eng.Engine(s, tc_groups=["System"], ref_t=[300.0], tau_t=[0.1], nsttcouple=10, nstcalcenergy=10, nstcomm=0, seed=11,
+                   pcoupl=1, **pk, **kw)
+    e.step(nst); e.synchronize()
+    er = e.energies(); _, presr = e.virial()
+    xr, _, boxr = e.get_state(); e.close()
+    boxr = np.asarray(boxr, dtype=np.float64).reshape(3, 3)
+    dx = o["x"] - xr
+    dx -= np.round(dx @ np.linalg.inv(boxr)) @ boxr
+    return dict(box_rel_diff=float(np.abs(o["box"] - boxr).max() / np.abs(boxr).max()),
+                box_change=float(abs(boxr[0, 0] / s.box[0][0] - 1.0)), dx_rms=float(np.sqrt((dx ** 2).mean())),
+                pot_dd=o["e"]["POT"], pot_single=er["POT"], pres_max_diff=float(np.abs(o["pres"] - presr).max()))
+
+
 def main(world=2, steps=12, d=7.0):
     import faulthandler; faulthandler.dump_traceback_later(int(os.environ.get("MDX_DD_LIMIT", "150")), exit=True)
     import mdx
@@ -79,6 +113,7 @@ def main(world=2, steps=12, d=7.0):
         res[label] = dict(dx_max=float(np.abs(dx).max()), dx_rms=float(np.sqrt((dx ** 2).mean())),
                           dv_rel_rms=float(np.sqrt(((o["v"] - vr) ** 2).mean() / (vr ** 2).mean())), partition=o["info"])
     res["coupled"] = coupled(world, 21, d)
+    res["npt"] = coupled_npt(world, 21, d)
     print(json.dumps(res), flush=True)
 
 

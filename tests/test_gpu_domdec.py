@@ -43,6 +43,13 @@ def test_domains_match_single_handle(world, box):
     assert c["vir_max_diff"] < 2e-4 * c["vir_scale"] and c["pres_max_diff"] < 3.0, c
     assert c["dv_rel_rms"] < 1e-3, c
     assert max(abs(v) for v in c["com_v"]) < 1e-5, c
+    # C-rescale across the domains (three coupling steps in 21): every domain draws the single handle's scaling factors
+    # from the summed pressure, so the cell ends where the single handle's does and the atoms with it
+    p = res["npt"]
+    assert p["box_change"] > 1e-7, p                      # the cell did move
+    assert p["box_rel_diff"] < 1e-6, p
+    assert p["dx_rms"] < 5e-6, p
+    assert abs(p["pot_dd"] - p["pot_single"]) < 2e-5 * abs(p["pot_single"]) and p["pres_max_diff"] < 3.0, p
 
 
 @pytest.mark.gpu
