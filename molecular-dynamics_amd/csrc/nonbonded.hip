@@ -87,7 +87,10 @@ __device__ __forceinline__ float mdx_pmecorr(float w)
 // 16: the LJ parameters of the i-atoms live in LDS (`ilj`, 64 float2 per wave) instead of 16 registers.
 // NI: i-clusters of the super-cluster held in registers at a time; NI = 4 walks the unit's entries twice (36 registers
 // fewer, j-atoms loaded and j-forces reduced twice), so that waves of other kernels fit beside the energy kernel.
-template <bool ENERGY, bool TIMED = false, int ABL = 0, int NI = 8>
+// WGT: pairs carry the weights 1, 1/2, 0 in energies and virial (a domain of a decomposed run: pairs with copies of other
+// domains' atoms); a compile-time switch, because the handful of extra instructions per tile costs the energy kernel a
+// third of its speed (304 against 227 us) and a single-domain run never needs them.
+template <bool ENERGY, bool TIMED = false, int ABL = 0, int NI = 8, bool WGT = false>
 __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nullptr, float2 *ilj = nullptr)
 {
     MDX_STAMP(A.dw, ENERGY ? 2 : 1);
@@ -287,7 +290,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                 if (ENERGY) {
                     // A pair between an atom of this domain and a copy of another domain's atom is evaluated by both
                     // owners: each takes half of its energy and virial; a pair of two copies belongs to others entirely.
-                    const float wgt = 1.0f - 0.5f * (float)((__float_as_uint(se_c) >> 31) + (__float_as_uint(lj.y) >> 31));
+                    const float wgt = WGT ? 1.0f - 0.5f * (float)((__float_as_uint(se_c) >> 31) + (__float_as_uint(lj.y) >> 31)) : 1.0f;
                     {
                         // statistics: pairs of real atoms (a filler carries a negative half-sigma) inside the cutoff
                         const bool counted = within && listed && hs_c >= 0.0f && lj.x >= 0.0f;
@@ -297,14 +300,24 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                     if (within && listed) {
                         const float c2 = sg * sg * (1.0f / rc2);
                         const float c6 = c2 * c2 * c2;
-                        elj = fmaf(wgt, t6 * (s6 - 1.0f) - e4 * c6 * (c6 - 1.0f), elj);
-                        ecoul = fmaf(wgt, qq * (erfc_br * rinv - A.c_rf_shift), ecoul);
+                        if (WGT) {
+                            elj = fmaf(wgt, t6 * (s6 - 1.0f) - e4 * c6 * (c6 - 1.0f), elj);
+                            ecoul = fmaf(wgt, qq * (erfc_br * rinv - A.c_rf_shift), ecoul);
+                        } else {
+                            elj += t6 * (s6 - 1.0f) - e4 * c6 * (c6 - 1.0f);
+                            ecoul += qq * (erfc_br * rinv - A.c_rf_shift);
+                        }
                     } else if (within) {
-                        eexcl = fmaf(wgt, e_ex, eexcl);
+                        if (WGT) eexcl = fmaf(wgt, e_ex, eexcl); else eexcl += e_ex;
                     }
-                    const float wx = wgt * fx, wy = wgt * fy, wz = wgt * fz;
-                    vxx = fmaf(dx, wx, vxx); vxy = fmaf(dx, wy, vxy); vxz = fmaf(dx, wz, vxz);
-                    vyy = fmaf(dy, wy, vyy); vyz = fmaf(dy, wz, vyz); vzz = fmaf(dz, wz, vzz);
+                    if (WGT) {
+                        const float wx = wgt * fx, wy = wgt * fy, wz = wgt * fz;
+                        vxx = fmaf(dx, wx, vxx); vxy = fmaf(dx, wy, vxy); vxz = fmaf(dx, wz, vxz);
+                        vyy = fmaf(dy, wy, vyy); vyz = fmaf(dy, wz, vyz); vzz = fmaf(dz, wz, vzz);
+                    } else {
+                        vxx = fmaf(dx, fx, vxx); vxy = fmaf(dx, fy, vxy); vxz = fmaf(dx, fz, vxz);
+                        vyy = fmaf(dy, fy, vyy); vyz = fmaf(dy, fz, vyz); vzz = fmaf(dz, fz, vzz);
+                    }
                 }
             };
             if (!general) {
@@ -451,6 +464,17 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __syncthreads();
     nb_body<true, false, 8 | 16, 4>(A, (const float2 *)tab4, ilj);
 }
+// The same with pair weights, for the domains of a decomposed run.
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_evt4w(NbArgs A)
+{
+    __shared__ float4 tab4[MDX_GTAB_N];
+    __shared__ float2 ilj[12 * 64];
+    const float4 *src = (const float4 *)A.htab;
+    for (int k = threadIdx.x; k < MDX_GTAB_N; k += 768) tab4[k] = src[k];
+    __syncthreads();
+    nb_body<true, false, 8 | 16, 4, true>(A, (const float2 *)tab4, ilj);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_evw(NbArgs A) { nb_body<true, false, 0, 8, true>(A); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3_abl1(NbArgs A) { nb_body<false, false, 1>(A); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3_abl2(NbArgs A) { nb_body<false, false, 2>(A); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3_timed(NbArgs A) { nb_body<false, true>(A); }
@@ -502,9 +526,9 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
     }
     void (*kern)(NbArgs) = k_nonbonded_f;
     dim3 grid(nblk), block(256);
-    if (energy && wv == 2) kern = k_nonbonded_ev2;
-    else if (energy && wv == 3 && s->htab && !(s->dbg & 0x400000)) { kern = (s->dbg & 0x1000000) ? k_nonbonded_evt : k_nonbonded_evt4; grid = dim3(256); block = dim3(768); }
-    else if (energy) kern = k_nonbonded_ev;
+    if (energy && wv == 2 && !s->dd_on) kern = k_nonbonded_ev2;
+    else if (energy && wv == 3 && s->htab && !(s->dbg & 0x400000)) { kern = s->dd_on ? k_nonbonded_evt4w : ((s->dbg & 0x1000000) ? k_nonbonded_evt : k_nonbonded_evt4); grid = dim3(256); block = dim3(768); }
+    else if (energy) kern = s->dd_on ? k_nonbonded_evw : k_nonbonded_ev;
     else if (wv == 2) kern = k_nonbonded_f2;
     else if (wv == 3) {
         if (s->nb_wave_t) kern = k_nonbonded_f3_timed;

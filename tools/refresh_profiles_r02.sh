@@ -9,7 +9,7 @@ timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout
 tail -2 $O/pytest_gpu.log
 timeout -k 10 200 python -c 'import __graft_entry__ as g; g.smoke()' > $O/smoke.log 2>&1 || { tail -20 $O/smoke.log; exit 1; }
 timeout -k 10 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err || { tail -5 $O/bench_default.err; exit 1; }
-timeout -k 10 300 python bench.py --steps 5000 --warmup 500 --no-cpu-baseline > $O/bench_5000.json 2> $O/bench_5000.err || exit 1
+timeout -k 10 300 python bench.py --steps 5000 --warmup 500 --no-cpu-baseline --pcoupl c-rescale > $O/bench_5000.json 2> $O/bench_5000.err || exit 1
 timeout -k 10 300 python bench.py --steps 5000 --warmup 500 --no-cpu-baseline --pcoupl parrinello-rahman > $O/bench_5000_pr.json 2> $O/bench_5000_pr.err || exit 1
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o p -- python3 $R/bench.py --steps 2000 --warmup 300 --no-cpu-baseline > $O/prof.log 2>&1 || { tail -5 $O/prof.log; exit 1; }

@@ -36,7 +36,8 @@ for lead, label in ((3, "plain step (step %% 20 == 3)"), (10, "energy step (step
     t = stamped(lead, 1, 0)
     t0 = t[0][0] if t[1][0] > 0 else min(v for v in t[0] if v < 2**62)
     print("---- %s" % label)
-    rows = [(t[0][k], t[1][k], NAMES.get(k, str(k))) for k in range(24) if t[1][k] > 0]
+    # (kernels that only the first of the two steps launched keep its stamps: they end before this step's prepare starts)
+    rows = [(t[0][k], t[1][k], NAMES.get(k, str(k))) for k in range(24) if t[1][k] > 0 and (t[1][k] >= t0 or lead == 0 or k == 3)]
     for a, b, n in sorted(rows):
         print("%8.1f %8.1f  %6.1f  %s" % ((a - t0) / 100.0, (b - t0) / 100.0, (b - a) / 100.0, n))
 # average step period from stamps over 40 steps: prepare start of first vs last is not kept, so time it from the host
