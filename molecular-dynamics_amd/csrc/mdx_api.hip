@@ -712,7 +712,10 @@ extern "C" int mdx_compute_forces(mdx_system *s, unsigned terms)
     if (terms & MDX_F_PME) if ((rc = mdx_launch_pme(s, true))) return rc;
     if ((rc = mdx_launch_bonded(s, true, terms))) return rc;
     if (terms & MDX_F_PULL) if ((rc = mdx_launch_pull(s, false, true))) return rc;
-    if ((rc = mdx_launch_nonbonded(s, true, terms))) return rc;
+    s->count_pairs = true;       // a single evaluation also reports the pair statistics
+    rc = mdx_launch_nonbonded(s, true, terms);
+    s->count_pairs = s->count_pairs_steps;
+    if (rc) return rc;
     if ((rc = mdx_join(s))) return rc;
     if ((rc = mdx_launch_ke(s, true, true))) return rc;
     if ((rc = mdx_launch_ke(s, false, true))) return rc;

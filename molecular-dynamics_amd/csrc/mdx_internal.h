@@ -239,6 +239,8 @@ struct mdx_system {
     double *ener_log = nullptr; int ener_log_cap = 0; long long ener_log_count = 0;
     // timing of the dominant kernel (HIP events on this stream)
     unsigned nb_launch_seq = 0;
+    bool count_pairs = false;          // the next launch of the energy kernel counts the pairs inside the cutoff (statistics)
+    bool count_pairs_steps = false;    // ... also on the energy steps of mdx_step (mdx_debug_set key 11); mdx_compute_forces always counts
     bool pme_signalled = false;        // ev_pme already attached to the last kernel of the PME chain
     bool time_nb = false; int time_stride = 7; std::vector<hipEvent_t> ev_pool; std::vector<std::pair<int, int>> ev_nb;
     double nb_ms_total = 0; long long nb_launches = 0;

@@ -90,7 +90,7 @@ __device__ __forceinline__ float mdx_pmecorr(float w)
 // WGT: pairs carry the weights 1, 1/2, 0 in energies and virial (a domain of a decomposed run: pairs with copies of other
 // domains' atoms); a compile-time switch, because the handful of extra instructions per tile costs the energy kernel a
 // third of its speed (304 against 227 us) and a single-domain run never needs them.
-template <bool ENERGY, bool TIMED = false, int ABL = 0, int NI = 8, bool WGT = false>
+template <bool ENERGY, bool TIMED = false, int ABL = 0, int NI = 8, bool WGT = false, bool COUNT = true>
 __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nullptr, float2 *ilj = nullptr)
 {
     MDX_STAMP(A.dw, ENERGY ? 2 : 1);
@@ -291,7 +291,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                     // A pair between an atom of this domain and a copy of another domain's atom is evaluated by both
                     // owners: each takes half of its energy and virial; a pair of two copies belongs to others entirely.
                     const float wgt = WGT ? 1.0f - 0.5f * (float)((__float_as_uint(se_c) >> 31) + (__float_as_uint(lj.y) >> 31)) : 1.0f;
-                    {
+                    if (COUNT) {
                         // statistics: pairs of real atoms (a filler carries a negative half-sigma) inside the cutoff
                         const bool counted = within && listed && hs_c >= 0.0f && lj.x >= 0.0f;
                         npair += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(counted));
@@ -464,6 +464,26 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __syncthreads();
     nb_body<true, false, 8 | 16, 4>(A, (const float2 *)tab4, ilj);
 }
+// The same without the pair statistics (the energy steps of mdx_step: only mdx_compute_forces and runs that ask for
+// them with mdx_debug_set key 11 count the pairs inside the cutoff).
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_evt4n(NbArgs A)
+{
+    __shared__ float4 tab4[MDX_GTAB_N];
+    __shared__ float2 ilj[12 * 64];
+    const float4 *src = (const float4 *)A.htab;
+    for (int k = threadIdx.x; k < MDX_GTAB_N; k += 768) tab4[k] = src[k];
+    __syncthreads();
+    nb_body<true, false, 8 | 16, 4, false, false>(A, (const float2 *)tab4, ilj);
+}
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_evtn(NbArgs A)
+{
+    __shared__ float4 tab4[MDX_GTAB_N];
+    __shared__ float2 ilj[12 * 64];
+    const float4 *src = (const float4 *)A.htab;
+    for (int k = threadIdx.x; k < MDX_GTAB_N; k += 768) tab4[k] = src[k];
+    __syncthreads();
+    nb_body<true, false, 8 | 16, 8, false, false>(A, (const float2 *)tab4, ilj);
+}
 // The same with pair weights, for the domains of a decomposed run.
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_evt4w(NbArgs A)
 {
@@ -527,7 +547,7 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
     void (*kern)(NbArgs) = k_nonbonded_f;
     dim3 grid(nblk), block(256);
     if (energy && wv == 2 && !s->dd_on) kern = k_nonbonded_ev2;
-    else if (energy && wv == 3 && s->htab && !(s->dbg & 0x400000)) { kern = s->dd_on ? k_nonbonded_evt4w : ((s->dbg & 0x1000000) ? k_nonbonded_evt : k_nonbonded_evt4); grid = dim3(256); block = dim3(768); }
+    else if (energy && wv == 3 && s->htab && !(s->dbg & 0x400000)) { kern = s->dd_on ? k_nonbonded_evt4w : ((s->dbg & 0x1000000) ? (s->count_pairs ? k_nonbonded_evt : k_nonbonded_evtn) : (s->count_pairs ? k_nonbonded_evt4 : k_nonbonded_evt4n)); grid = dim3(256); block = dim3(768); }
     else if (energy) kern = s->dd_on ? k_nonbonded_evw : k_nonbonded_ev;
     else if (wv == 2) kern = k_nonbonded_f2;
     else if (wv == 3) {
@@ -615,6 +635,7 @@ extern "C" int mdx_debug_set(mdx_system *s, int key, int value)
     if (key == 6) { s->bond_on_main = value; return MDX_OK; }
     if (key == 5) { s->early_fork = value; return MDX_OK; }
     if (key == 4 && value >= 0 && value <= 3) { s->nb_dyn_split = value; return MDX_OK; }
+    if (key == 11) { s->count_pairs_steps = s->count_pairs = value != 0; return MDX_OK; }     // energy steps of mdx_step count the pairs inside the cutoff
     if (key == 10) {      // streams per handle: 1 (every kernel in one stream's order) or 3
         if (value != 1 && value != 3) { s->err = "mdx_debug_set: key 10 takes 1 or 3"; return MDX_ERR_ARG; }
         return mdx_set_stream_mode(s, value == 1);
