@@ -337,7 +337,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
             if (did && !(ABL & 2)) { fjx = sum8(fjx); fjy = sum8(fjy); fjz = sum8(fjz); }
             // (one 24-lane atomic per entry: pairing two entries into one 48-lane atomic costs more VALU instructions in
             // the selects than the second atomic costs now that no wait sits behind it)
-            if (did && ti < 3 && !(A.dbg & 0x20000)) atomicAdd(at32(A.f_s, (unsigned)(3 * (cj * 8 + tj) + ti)), (ti == 0) ? fjx : ((ti == 1) ? fjy : fjz));
+            if (did && ti < 3 && !((ABL & 64) && (A.dbg & 0x20000))) atomicAdd(at32(A.f_s, (unsigned)(3 * (cj * 8 + tj) + ti)), (ti == 0) ? fjx : ((ti == 1) ? fjy : fjz));
         };
         JSet Ja, Jb;
         fetch(Ja, 0);
@@ -355,7 +355,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
             ax += dpp_row_ror8(ax); ay += dpp_row_ror8(ay); az += dpp_row_ror8(az);
             ax += __shfl_xor(ax, 16, 64); ay += __shfl_xor(ay, 16, 64); az += __shfl_xor(az, 16, 64);
             ax += __shfl_xor(ax, 32, 64); ay += __shfl_xor(ay, 32, 64); az += __shfl_xor(az, 32, 64);
-            if (tj < 3 && !(A.dbg & 0x40000)) {
+            if (tj < 3 && !((ABL & 64) && (A.dbg & 0x40000))) {
                 const float val = (tj == 0) ? ax : ((tj == 1) ? ay : az);
                 atomicAdd(at32(A.f_s, (unsigned)(3 * ((sci * 8 + c0 + c) * 8 + ti) + tj)), val);
             }
@@ -423,6 +423,17 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int k = threadIdx.x; k < MDX_GTAB_N / 2; k += 768) tab4[k] = src[k];
     __syncthreads();
     nb_body<false, false, 4 | 16>(A, (const float2 *)tab4, ilj);
+}
+// The same with the run-time switches that leave out the force atomics (timing experiments: mdx_debug_set key 2, bits
+// 0x20000 and 0x40000); the production kernel does not carry their tests.
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_f3tl_abl(NbArgs A)
+{
+    __shared__ float4 tab4[MDX_GTAB_N / 2];
+    __shared__ float2 ilj[12 * 64];
+    const float4 *src = (const float4 *)A.gtab;
+    for (int k = threadIdx.x; k < MDX_GTAB_N / 2; k += 768) tab4[k] = src[k];
+    __syncthreads();
+    nb_body<false, false, 4 | 16 | 64>(A, (const float2 *)tab4, ilj);
 }
 // Four i-clusters at a time (two passes over the unit's entries) at four waves per SIMD: a quarter fewer registers per
 // wave, a third more waves to cover the LDS and memory latencies.
@@ -555,7 +566,7 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
         else if (s->dbg & 0x100000) kern = k_nonbonded_f3_abl1;
         else if (s->dbg & 0x200000) kern = k_nonbonded_f3_abl2;
         else if ((s->dbg & 0x400000) || !s->gtab) kern = k_nonbonded_f3;
-        else { kern = (s->dbg & 0x800000) ? k_nonbonded_f3t128 : ((s->dbg & 0x4000000) ? k_nonbonded_f3t : k_nonbonded_f3tl); grid = dim3(256); block = dim3(768); }
+        else { kern = (s->dbg & 0x800000) ? k_nonbonded_f3t128 : ((s->dbg & 0x4000000) ? k_nonbonded_f3t : ((s->dbg & 0x60000) ? k_nonbonded_f3tl_abl : k_nonbonded_f3tl)); grid = dim3(256); block = dim3(768); }
     } else if (wv == 4 && s->gtab && !(s->dbg & 0x400000)) { kern = k_nonbonded_f4tl4; grid = dim3(256); block = dim3(1024); }
     hipExtLaunchKernelGGL(kern, grid, block, 0, s->stream, ev_a, ev_b, 0, A);
     MDX_CHECK(s, hipGetLastError());
