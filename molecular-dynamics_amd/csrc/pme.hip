@@ -552,6 +552,93 @@ __device__ __forceinline__ void dft_lines(float2 *a, float2 *b, const float2 *W,
     __syncthreads();
 }
 
+// The same transform with the small DFTs of a pass done by one thread each: a thread loads the R inputs of one small DFT
+// into registers once and forms its R outputs from them, the R-th roots of unity in scalar registers (they are the same
+// for every lane) and every index known at compile time. That is 4 R multiply-adds per output point and one LDS read per
+// input point, where the one-output-per-thread form above spends about ten instructions and two LDS reads per
+// multiply-add on loads and index arithmetic - and the transforms run beside the nonbonded kernel, which leaves them few
+// issue slots. Radices up to 10 (every factor pair of the PME grids up to 100 points); other lines take the form above.
+#define MDX_DFT_MAXR 10
+template <int R>
+__device__ __forceinline__ void dft_roots(const float2 *W, int N, float sgn, float (&wr)[R], float (&wi)[R])
+{
+    // exp(-+ 2 pi i m / R), m < R, as wave-uniform values
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        const float2 w = W[m * (N / R)];
+        wr[m] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w.x)));
+        wi[m] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sgn * w.y)));
+    }
+}
+// pass 1 with N1 = R: b[k1 N2 + n2] = W_N^(n2 k1) sum_n1 a[N2 n1 + n2] W_R^(n1 k1)
+template <int R>
+__device__ __forceinline__ void dft_pass1_r(const float2 *a, float2 *b, const float2 *W, int nl, int N, int N2, float sgn)
+{
+    float wr[R], wi[R];
+    dft_roots<R>(W, N, sgn, wr, wi);
+    const int stride = N + 1;
+    for (int idx = threadIdx.x; idx < nl * N2; idx += blockDim.x) {
+        const int line = idx / N2, n2 = idx - line * N2;
+        const float2 *x = a + line * stride + n2;
+        float xr[R], xi[R];
+#pragma unroll
+        for (int n1 = 0; n1 < R; n1++) { const float2 v = x[n1 * N2]; xr[n1] = v.x; xi[n1] = v.y; }
+        float2 *o = b + line * stride + n2;
+#pragma unroll
+        for (int k1 = 0; k1 < R; k1++) {
+            float re = xr[0], im = xi[0];
+#pragma unroll
+            for (int n1 = 1; n1 < R; n1++) {
+                const int m = (n1 * k1) % R;
+                re = fmaf(xr[n1], wr[m], fmaf(-xi[n1], wi[m], re));
+                im = fmaf(xr[n1], wi[m], fmaf(xi[n1], wr[m], im));
+            }
+            const float2 t = W[n2 * k1]; const float ty = sgn * t.y;
+            o[k1 * N2] = make_float2(re * t.x - im * ty, re * ty + im * t.x);
+        }
+    }
+}
+// pass 2 with N2 = R: a[k1 + N1 k2] = sum_n2 b[k1 N2 + n2] W_R^(n2 k2)
+template <int R>
+__device__ __forceinline__ void dft_pass2_r(float2 *a, const float2 *b, const float2 *W, int nl, int N, int N1, float sgn)
+{
+    float wr[R], wi[R];
+    dft_roots<R>(W, N, sgn, wr, wi);
+    const int stride = N + 1;
+    for (int idx = threadIdx.x; idx < nl * N1; idx += blockDim.x) {
+        const int line = idx / N1, k1 = idx - line * N1;
+        const float2 *x = b + line * stride + k1 * R;
+        float xr[R], xi[R];
+#pragma unroll
+        for (int n2 = 0; n2 < R; n2++) { const float2 v = x[n2]; xr[n2] = v.x; xi[n2] = v.y; }
+        float2 *o = a + line * stride + k1;
+#pragma unroll
+        for (int k2 = 0; k2 < R; k2++) {
+            float re = xr[0], im = xi[0];
+#pragma unroll
+            for (int n2 = 1; n2 < R; n2++) {
+                const int m = (n2 * k2) % R;
+                re = fmaf(xr[n2], wr[m], fmaf(-xi[n2], wi[m], re));
+                im = fmaf(xr[n2], wi[m], fmaf(xi[n2], wr[m], im));
+            }
+            o[N1 * k2] = make_float2(re, im);
+        }
+    }
+}
+#define MDX_DFT_CASES(F, ...) \
+    case 2: F<2>(__VA_ARGS__); break; case 3: F<3>(__VA_ARGS__); break; case 4: F<4>(__VA_ARGS__); break; \
+    case 5: F<5>(__VA_ARGS__); break; case 6: F<6>(__VA_ARGS__); break; case 7: F<7>(__VA_ARGS__); break; \
+    case 8: F<8>(__VA_ARGS__); break; case 9: F<9>(__VA_ARGS__); break; case 10: F<10>(__VA_ARGS__); break;
+__device__ __forceinline__ void dft_lines_fast(float2 *a, float2 *b, const float2 *W, int nl, int N, int N1, int N2, bool inverse)
+{
+    if (N1 < 2 || N1 > MDX_DFT_MAXR || N2 < 2 || N2 > MDX_DFT_MAXR) { dft_lines(a, b, W, nl, N, N1, N2, inverse); return; }
+    const float sgn = inverse ? -1.0f : 1.0f;
+    switch (N1) { MDX_DFT_CASES(dft_pass1_r, a, b, W, nl, N, N2, sgn) }
+    __syncthreads();
+    switch (N2) { MDX_DFT_CASES(dft_pass2_r, a, b, W, nl, N, N1, sgn) }
+    __syncthreads();
+}
+
 // The same two passes for lines laid out with strides: element n of line l at a[l * ls + n * es]. With LINE_FAST
 // consecutive threads take consecutive lines (for es > 1, where consecutive n would collide on LDS banks).
 template <bool LINE_FAST>
@@ -693,7 +780,7 @@ __global__ __launch_bounds__(256) void k_pme_fft(FftArgs A)
             }
         }
         __syncthreads();
-        dft_lines(a, b, Wl, nl, N, A.N1, A.N2, MODE == 4);
+        dft_lines_fast(a, b, Wl, nl, N, A.N1, A.N2, MODE == 4);
         if (MODE == 0) {
             for (int idx = threadIdx.x; idx < nl * K0c; idx += blockDim.x) {
                 const int l = idx / K0c, k = idx - l * K0c;
@@ -717,7 +804,7 @@ __global__ __launch_bounds__(256) void k_pme_fft(FftArgs A)
         a[c * stride + n] = (kx0 + c < K0c) ? A.cgrid[base + (size_t)n * estride + kx0 + c] : make_float2(0.0f, 0.0f);
     }
     __syncthreads();
-    dft_lines(a, b, Wl, nl, N, A.N1, A.N2, MODE == 3);
+    dft_lines_fast(a, b, Wl, nl, N, A.N1, A.N2, MODE == 3);
     if (MODE == 2) {
         // influence function on (kx0 + c, y = other, kz = n); energy and virial as in the stand-alone solve kernel
         double e = 0.0, v[6] = { 0, 0, 0, 0, 0, 0 };
@@ -767,7 +854,7 @@ __global__ __launch_bounds__(256) void k_pme_fft(FftArgs A)
             }
         }
         __syncthreads();
-        dft_lines(a, b, Wl, nl, N, A.N1, A.N2, true);
+        dft_lines_fast(a, b, Wl, nl, N, A.N1, A.N2, true);
     }
     for (int idx = threadIdx.x; idx < nl * N; idx += blockDim.x) {
         const int n = idx / nl, c = idx - n * nl;
