@@ -7,10 +7,23 @@
 // molecule; restraints and exclusion pairs use the triclinic minimum image.
 #include "mdx_internal.h"
 
-__device__ __forceinline__ void add_force(float *f, int i, float3 v)
-{
-    atomicAdd(&f[3 * i + 0], v.x); atomicAdd(&f[3 * i + 1], v.y); atomicAdd(&f[3 * i + 2], v.z);
-}
+// Forces of a workgroup's interactions are summed in LDS first. The interactions of a topology come in atom order, so
+// the 256 interactions of a workgroup touch a short range of atoms; a window of MDX_BWIN atoms starting at the lowest
+// atom index of the workgroup collects them (LDS float atomics), and only its non-zero entries go to the force array
+// with global atomics: a tenth of the global atomics, and far fewer of them on one address. Global float atomics are
+// carried out at the memory side, where these (75 per protein atom before) also held up the flush of the charge
+// spreading that runs at the same time (spreading 53 -> 30 us beside it). Atoms outside the window are added directly.
+#define MDX_BWIN 1024
+struct ForceWin {
+    float *win; int base; float *f;
+    __device__ __forceinline__ void add(int i, float3 v) const
+    {
+        const unsigned int k = (unsigned int)(i - base);
+        if (k < (unsigned int)MDX_BWIN) { atomicAdd(&win[3 * k + 0], v.x); atomicAdd(&win[3 * k + 1], v.y); atomicAdd(&win[3 * k + 2], v.z); }
+        else { atomicAdd(&f[3 * i + 0], v.x); atomicAdd(&f[3 * i + 1], v.y); atomicAdd(&f[3 * i + 2], v.z); }
+    }
+};
+__device__ __forceinline__ void add_force(const ForceWin &f, int i, float3 v) { f.add(i, v); }
 
 // Block-reduce an energy and a 3x3 virial contribution (sum d (x) F, not yet scaled by -1/2).
 __device__ void accum_ev(double e, const float *v9, DevState *dw, int eidx, double e2 = 0.0, int eidx2 = -1)
@@ -37,7 +50,7 @@ __device__ __forceinline__ void outer_acc(float *v9, float3 d, float3 f)
 
 template <bool ENERGY>
 __device__ __forceinline__ void d_bonds(int t, int n, const int2 *__restrict__ ij, const float2 *__restrict__ p,
-                                               const float4 *__restrict__ x, float *__restrict__ f, DevState *dw)
+                                               const float4 *__restrict__ x, const ForceWin &f, DevState *dw)
 {
     double e = 0.0; float v9[9] = { 0 };
     if (t < n) {
@@ -54,7 +67,7 @@ __device__ __forceinline__ void d_bonds(int t, int n, const int2 *__restrict__ i
 
 template <bool ENERGY>
 __device__ __forceinline__ void d_angles(int t, int n, const int4 *__restrict__ ijk, const float2 *__restrict__ p,
-                                                const float4 *__restrict__ x, float *__restrict__ f, DevState *dw)
+                                                const float4 *__restrict__ x, const ForceWin &f, DevState *dw)
 {
     double e = 0.0; float v9[9] = { 0 };
     if (t < n) {
@@ -79,7 +92,7 @@ __device__ __forceinline__ void d_angles(int t, int n, const int4 *__restrict__ 
 
 template <bool ENERGY>
 __device__ __forceinline__ void d_dihedrals(int t, int n, const int4 *__restrict__ ijkl, const float4 *__restrict__ p,
-                                                   const float4 *__restrict__ x, float *__restrict__ f, DevState *dw)
+                                                   const float4 *__restrict__ x, const ForceWin &f, DevState *dw)
 {
     double e = 0.0; float v9[9] = { 0 };
     if (t < n) {
@@ -114,7 +127,7 @@ __device__ __forceinline__ void d_dihedrals(int t, int n, const int4 *__restrict
 
 template <bool ENERGY>
 __device__ __forceinline__ void d_pairs14(int t, int n, const int2 *__restrict__ ij, const float4 *__restrict__ p,
-                                                 const float4 *__restrict__ x, float *__restrict__ f, DevState *dw)
+                                                 const float4 *__restrict__ x, const ForceWin &f, DevState *dw)
 {
     double e = 0.0, e2 = 0.0; float v9[9] = { 0 };
     if (t < n) {
@@ -134,7 +147,7 @@ __device__ __forceinline__ void d_pairs14(int t, int n, const int2 *__restrict__
 template <bool ENERGY>
 __device__ __forceinline__ void d_posres(int t, int n, const int *__restrict__ idx, const float4 *__restrict__ ref,
                                                 const float4 *__restrict__ kk, const float4 *__restrict__ x,
-                                                float *__restrict__ f, DevState *dw, int refcoord_scaling)
+                                                const ForceWin &f, DevState *dw, int refcoord_scaling)
 {
     double e = 0.0; float v9[9] = { 0 };
     if (t < n) {
@@ -176,12 +189,37 @@ template <bool ENERGY>
 __global__ __launch_bounds__(256) void k_bonded(BondedArgs A)
 {
     MDX_STAMP(A.dw, 10);
+    __shared__ float win[3 * MDX_BWIN];
+    __shared__ int s_base;
     const int b = blockIdx.x;
-    if (b < A.nb[1]) d_bonds<ENERGY>((b - A.nb[0]) * 256 + threadIdx.x, A.nbonds, A.bond_ij, A.bond_p, A.x, A.f, A.dw);
-    else if (b < A.nb[2]) d_angles<ENERGY>((b - A.nb[1]) * 256 + threadIdx.x, A.nangles, A.angle_ijk, A.angle_p, A.x, A.f, A.dw);
-    else if (b < A.nb[3]) d_dihedrals<ENERGY>((b - A.nb[2]) * 256 + threadIdx.x, A.ndih, A.dih_ijkl, A.dih_p, A.x, A.f, A.dw);
-    else if (b < A.nb[4]) d_pairs14<ENERGY>((b - A.nb[3]) * 256 + threadIdx.x, A.npairs, A.pair_ij, A.pair_p, A.x, A.f, A.dw);
-    else d_posres<ENERGY>((b - A.nb[4]) * 256 + threadIdx.x, A.nposres, A.posres_idx, A.posres_ref, A.posres_k, A.x, A.f, A.dw, A.refcoord_scaling);
+    // lowest atom index among the workgroup's interactions (first index of each tuple: tuples are written in ascending order
+    // of their atoms often enough; the others only miss the window and take the direct path)
+    if (threadIdx.x == 0) s_base = 0x7fffffff;
+    for (int k = threadIdx.x; k < 3 * MDX_BWIN; k += 256) win[k] = 0.0f;
+    __syncthreads();
+    int t, lo = 0x7fffffff;
+    if (b < A.nb[1]) { t = (b - A.nb[0]) * 256 + threadIdx.x; if (t < A.nbonds) { const int2 a = A.bond_ij[t]; lo = min(a.x, a.y); } }
+    else if (b < A.nb[2]) { t = (b - A.nb[1]) * 256 + threadIdx.x; if (t < A.nangles) { const int4 a = A.angle_ijk[t]; lo = min(a.x, min(a.y, a.z)); } }
+    else if (b < A.nb[3]) { t = (b - A.nb[2]) * 256 + threadIdx.x; if (t < A.ndih) { const int4 a = A.dih_ijkl[t]; lo = min(min(a.x, a.y), min(a.z, a.w)); } }
+    else if (b < A.nb[4]) { t = (b - A.nb[3]) * 256 + threadIdx.x; if (t < A.npairs) { const int2 a = A.pair_ij[t]; lo = min(a.x, a.y); } }
+    else { t = (b - A.nb[4]) * 256 + threadIdx.x; if (t < A.nposres) lo = A.posres_idx[t]; }
+    for (int o = 32; o > 0; o >>= 1) lo = min(lo, __shfl_xor(lo, o, 64));
+    if ((threadIdx.x & 63) == 0 && lo != 0x7fffffff) atomicMin(&s_base, lo);
+    __syncthreads();
+    ForceWin F; F.win = win; F.base = s_base; F.f = A.f;
+    if (b < A.nb[1]) d_bonds<ENERGY>(t, A.nbonds, A.bond_ij, A.bond_p, A.x, F, A.dw);
+    else if (b < A.nb[2]) d_angles<ENERGY>(t, A.nangles, A.angle_ijk, A.angle_p, A.x, F, A.dw);
+    else if (b < A.nb[3]) d_dihedrals<ENERGY>(t, A.ndih, A.dih_ijkl, A.dih_p, A.x, F, A.dw);
+    else if (b < A.nb[4]) d_pairs14<ENERGY>(t, A.npairs, A.pair_ij, A.pair_p, A.x, F, A.dw);
+    else d_posres<ENERGY>(t, A.nposres, A.posres_idx, A.posres_ref, A.posres_k, A.x, F, A.dw, A.refcoord_scaling);
+    __syncthreads();
+    if (F.base != 0x7fffffff) {
+        float *dst = A.f + 3 * (size_t)F.base;
+        for (int k = threadIdx.x; k < 3 * MDX_BWIN; k += 256) {
+            const float v = win[k];
+            if (v != 0.0f) atomicAdd(&dst[k], v);
+        }
+    }
 }
 
 int mdx_launch_bonded(mdx_system *s, bool energy, unsigned flags)
