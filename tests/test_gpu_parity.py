@@ -87,6 +87,48 @@ def test_bonded_terms(eng_complex, small_complex):
     e.set_state(s.x, s.v, s.box)
 
 
+def test_bonded_terms_across_distant_atom_indices(small_complex):
+    """Bonds, angles and dihedrals whose atoms lie thousands of indices apart (cross-links, interactions listed out of
+    atom order): the bonded kernel sums a workgroup's forces in an LDS window over 1024 atom indices from the lowest one
+    it sees and adds everything outside that window to the force array directly; both paths against the oracle."""
+    import copy
+    s = copy.deepcopy(small_complex)
+    n = s.natoms
+    assert n > 5000
+    rng = np.random.default_rng(11)
+    lo = rng.integers(0, 200, size=40); hi = n - 1 - rng.integers(0, 200, size=40)
+    mid = n // 2 + rng.integers(-100, 100, size=40)
+    s.bonds = np.concatenate([s.bonds, np.stack([lo, hi], 1).astype(np.int32)])
+    s.bond_b0 = np.concatenate([s.bond_b0, np.full(40, 2.5)]); s.bond_kb = np.concatenate([s.bond_kb, np.full(40, 5.0)])
+    s.angles = np.concatenate([s.angles, np.stack([hi, lo, mid], 1).astype(np.int32)])
+    s.angle_th0 = np.concatenate([s.angle_th0, np.full(40, 1.9)]); s.angle_k = np.concatenate([s.angle_k, np.full(40, 1.0)])
+    s.dihedrals = np.concatenate([s.dihedrals, np.stack([hi, mid, lo, lo + 300], 1).astype(np.int32)])
+    s.dih_phi0 = np.concatenate([s.dih_phi0, np.full(40, 0.3)]); s.dih_k = np.concatenate([s.dih_k, np.full(40, 0.5)])
+    s.dih_mult = np.concatenate([s.dih_mult, np.full(40, 2, dtype=s.dih_mult.dtype)])
+    e = eng.Engine(s, rc=1.0, nstcalcenergy=1, use_posres=True)
+    try:
+        # thermal-like distortion as in test_bonded_terms (at the undistorted geometry the bonded forces nearly cancel and
+        # float32 trigonometry shows at 2e-5 of what is left)
+        x = (s.x + np.random.default_rng(7).normal(scale=0.004, size=s.x.shape)).astype(np.float32).astype(np.float64)
+        e.set_state(x, None, s.box)
+        f, en = e.compute(eng.F_BONDED)
+        eb, fb, _ = R.bonds(x, s.bonds, s.bond_b0, s.bond_kb)
+        ea, fa, _ = R.angles(x, s.angles, s.angle_th0, s.angle_k)
+        ed, fd, _ = R.dihedrals(x, s.dihedrals, s.dih_phi0, s.dih_k, s.dih_mult)
+        el, ec, fp, _ = R.pairs14(x, s.pairs14, s.pair_c6, s.pair_c12, s.pair_qq)
+        ref = fb + fa + fd + fp
+        assert relrms(f, ref) < FTOL
+        for name, ee in (("BOND", eb), ("ANGLE", ea), ("DIH", ed)):
+            assert abs(en[name] - ee) < ETOL * max(abs(ee), 1.0), name
+        # the far ends (water atoms at the top of the index range, which carry nothing but these cross-links) did receive
+        # their forces: float32 trigonometry on nanometre-long arms limits them to 1e-4
+        far = np.unique(hi)
+        assert np.abs(ref[far]).max() > 0
+        assert relrms(f[far], ref[far]) < 1e-4
+    finally:
+        e.close()
+
+
 def test_total_force_and_newton(eng_complex, small_complex):
     e, s = eng_complex, small_complex
     f, en = e.compute(eng.F_ALL & ~eng.F_PULL & ~eng.F_POSRES)
