@@ -670,12 +670,12 @@ extern "C" int mdx_set_run_state(mdx_system *s, const double *rs)
 }
 
 // ---------------------------------------------------------------- compute
-static int record_energy_frame(mdx_system *s)
+// Next slot of the pinned ring of energy frames: the kernel that finishes the energies writes the frame there itself.
+static double *next_energy_frame(mdx_system *s)
 {
     const long long slot = s->ener_log_count % s->ener_log_cap;
-    MDX_CHECK(s, hipMemcpyAsync(s->ener_log + slot * MDX_E_N, s->d->ener, sizeof(double) * MDX_E_N, hipMemcpyDeviceToHost, s->stream));
     s->ener_log_count++;
-    return MDX_OK;
+    return s->ener_log + slot * MDX_E_N;
 }
 
 static std::vector<long long> &frame_steps(mdx_system *s) { return s->frame_steps; }
@@ -916,14 +916,10 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early)
     }
     if (need_vir) {
         if ((rc = mdx_launch_ke(s, false, true))) return rc;
-        if ((rc = mdx_launch_finish_energy(s))) return rc;
-        if (do_ener) {
-            if ((rc = record_energy_frame(s))) return rc;
-            frame_steps(s).push_back(step);
-        }
+        // (a domain of a decomposed run leaves the scaling to the caller, who sums the pressure over the domains first: mdx_dd_pcouple)
+        if ((rc = mdx_launch_finish_energy(s, do_ener ? next_energy_frame(s) : nullptr, do_pc && !s->dd_on))) return rc;
+        if (do_ener) frame_steps(s).push_back(step);
     }
-    // (a domain of a decomposed run leaves the scaling to the caller, who sums the pressure over the domains first: mdx_dd_pcouple)
-    if (do_pc && !s->dd_on) if ((rc = mdx_launch_pcouple(s))) return rc;
     if (s->ntc > 0 && ((step + 1) % s->nsttcouple == 0)) {
         if (!need_vir) {
             if ((rc = mdx_launch_clear(s, false, true, false))) return rc;

@@ -286,7 +286,7 @@ int mdx_launch_clear(mdx_system *s, bool energies, bool ekin_new, bool ekin_old)
 int mdx_launch_tcouple(mdx_system *s);
 int mdx_launch_pcouple(mdx_system *s);
 int mdx_launch_comm(mdx_system *s);
-int mdx_launch_finish_energy(mdx_system *s);
+int mdx_launch_finish_energy(mdx_system *s, double *frame = nullptr, bool with_pcouple = false);
 int mdx_launch_merge_forces(mdx_system *s, float *out3n);
 int mdx_pme_init(mdx_system *s);
 void mdx_pme_free(mdx_system *s);

@@ -322,10 +322,16 @@ __global__ void k_tcouple(DevState *dw, int ntc, const double *ref_t, const doub
     }
 }
 
+// Barostat parameters of one coupling step (kind 0: none).
+struct PcoupleArgs { int kind; double tau_p, ref_p, compress, dt_pc, kT; unsigned long long seed; long long step; };
+__device__ void pcouple_scalars(DevState *dw, int kind, double tau_p, double ref_p, double compress, double dt_pc, double kT,
+                                unsigned long long seed, long long step);
+
 // Finish an energy step: kinetic energy as the leap-frog average, temperature, pressure tensor,
-// dispersion correction, totals and the conserved quantity.
+// dispersion correction, totals and the conserved quantity. `frame` (pinned host memory, or null) receives a copy of
+// the finished energy terms; with pc.kind != 0 the barostat's scalars of this step follow in the same launch.
 __global__ void k_finish_energy(DevState *dw, int ntc, double ndf_total, int dispcorr, double c6avg, int natoms,
-                                double rc, double q2sum, double beta, int have_pme)
+                                double rc, double q2sum, double beta, int have_pme, double *__restrict__ frame, PcoupleArgs pc)
 {
     // fold the replicated accumulators (one quantity per thread), then thread 0 finishes
     {
@@ -340,7 +346,8 @@ __global__ void k_finish_energy(DevState *dw, int ntc, double ndf_total, int dis
         }
     }
     __syncthreads();
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0) return;
+    if (threadIdx.x == 0) {
     const int ng = ntc > 0 ? ntc : 1;
     double ek = 0.0;
     for (int g = 0; g < ng; g++) ek += 0.5 * (dw->ekinh_old[g] + dw->ekinh[g]);
@@ -369,15 +376,19 @@ __global__ void k_finish_energy(DevState *dw, int ntc, double ndf_total, int dis
     double cons = pot + ek + dw->baro_integral;
     for (int g = 0; g < ng; g++) cons += dw->therm_integral[g];
     dw->ener[MDX_E_CONSERVED] = cons;
+    }
+    __syncthreads();
+    if (frame && threadIdx.x < MDX_E_N) frame[threadIdx.x] = dw->ener[threadIdx.x];
+    if (threadIdx.x != 0) return;
+    if (pc.kind) pcouple_scalars(dw, pc.kind, pc.tau_p, pc.ref_p, pc.compress, pc.dt_pc, pc.kT, pc.seed, pc.step);
 }
 
 // Barostat scalars (one thread). kind 1: C-rescale (Bernetti & Bussi 2020), isotropic:
 //   d eps = -(beta/tau_p)(P0 - P) dt + sqrt(2 kT beta dt / (V tau_p)) dW,  mu = exp(d eps / 3).
 // kind 2: Parrinello-Rahman, isotropic: box-velocity ODE with W^-1 = 4 pi^2 beta / (3 tau_p^2 L).
-__global__ void k_pcouple(DevState *dw, int kind, double tau_p, double ref_p, double compress, double dt_pc, double kT,
-                          unsigned long long seed, long long step)
+__device__ void pcouple_scalars(DevState *dw, int kind, double tau_p, double ref_p, double compress, double dt_pc, double kT,
+                                unsigned long long seed, long long step)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double *b = dw->boxd;
     const double vol = b[0] * b[4] * b[8];
     const double P = (dw->pres[0] + dw->pres[4] + dw->pres[8]) / 3.0;
@@ -438,6 +449,12 @@ __global__ void k_pcouple(DevState *dw, int kind, double tau_p, double ref_p, do
     nb.vol = (float)(b[0] * b[4] * b[8]);
     for (int a = 0; a < 5; a++) nb.pad[a] = 0.0f;
     dw->box = nb;
+}
+
+__global__ void k_pcouple(DevState *dw, PcoupleArgs pc)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    pcouple_scalars(dw, pc.kind, pc.tau_p, pc.ref_p, pc.compress, pc.dt_pc, pc.kT, pc.seed, pc.step);
 }
 
 // Scale coordinates (and restraint references) by mu; C-rescale also scales velocities by 1/mu.
@@ -588,28 +605,44 @@ int mdx_launch_tcouple(mdx_system *s)
     return MDX_OK;
 }
 
-int mdx_launch_finish_energy(mdx_system *s)
+static PcoupleArgs pcouple_args(mdx_system *s)
 {
-    double ndf_total = 0;
-    for (int g = 0; g < s->ntc; g++) ndf_total += s->ndf[g];
-    if (s->ntc == 0) ndf_total = s->ndf_total;
-    hipLaunchKernelGGL(k_finish_energy, dim3(1), dim3(64), 0, s->stream, s->d, s->ntc, ndf_total, s->dispcorr, s->dispcorr_c6avg,
-                       s->n, (double)s->rc, s->q2sum, (double)s->beta, s->have_pme ? 1 : 0);
-    MDX_CHECK(s, hipGetLastError());
-    return MDX_OK;
+    PcoupleArgs pc;
+    pc.kind = s->pcoupl; pc.tau_p = s->tau_p; pc.ref_p = s->ref_p; pc.compress = s->compress;
+    pc.dt_pc = (double)s->nstpcouple * s->dt; pc.kT = MDX_BOLTZ * (s->ntc > 0 ? s->ref_t[0] : 300.0);
+    pc.seed = (unsigned long long)s->seed; pc.step = s->step;
+    return pc;
 }
 
-int mdx_launch_pcouple(mdx_system *s)
+static int launch_scale(mdx_system *s)
 {
-    if (s->pcoupl == 0) return MDX_OK;
-    const double kT = MDX_BOLTZ * (s->ntc > 0 ? s->ref_t[0] : 300.0);
-    hipLaunchKernelGGL(k_pcouple, dim3(1), dim3(64), 0, s->stream, s->d, s->pcoupl, s->tau_p, s->ref_p, s->compress,
-                       (double)s->nstpcouple * s->dt, kT, (unsigned long long)s->seed, s->step);
     const int nb = (std::max(s->n, s->nposres) + 255) / 256;
     hipLaunchKernelGGL(k_scale, dim3(nb), dim3(256), 0, s->stream, s->n, s->x, s->v, s->d, s->pcoupl == 1 ? 1 : 0,
                        s->refcoord_scaling ? s->nposres : 0, s->posres_ref, s->refcoord_scaling);
     MDX_CHECK(s, hipGetLastError());
     return MDX_OK;
+}
+
+// frame: pinned host destination of the finished energy terms (null: none); with_pcouple: the barostat's scalars and
+// the scaling of coordinates follow (what mdx_launch_pcouple would do after this call).
+int mdx_launch_finish_energy(mdx_system *s, double *frame, bool with_pcouple)
+{
+    double ndf_total = 0;
+    for (int g = 0; g < s->ntc; g++) ndf_total += s->ndf[g];
+    if (s->ntc == 0) ndf_total = s->ndf_total;
+    PcoupleArgs pc = pcouple_args(s);
+    if (!with_pcouple) pc.kind = 0;
+    hipLaunchKernelGGL(k_finish_energy, dim3(1), dim3(64), 0, s->stream, s->d, s->ntc, ndf_total, s->dispcorr, s->dispcorr_c6avg,
+                       s->n, (double)s->rc, s->q2sum, (double)s->beta, s->have_pme ? 1 : 0, frame, pc);
+    MDX_CHECK(s, hipGetLastError());
+    return with_pcouple ? launch_scale(s) : MDX_OK;
+}
+
+int mdx_launch_pcouple(mdx_system *s)
+{
+    if (s->pcoupl == 0) return MDX_OK;
+    hipLaunchKernelGGL(k_pcouple, dim3(1), dim3(64), 0, s->stream, s->d, pcouple_args(s));
+    return launch_scale(s);
 }
 
 // phase 0: momentum and mass sums into DevState::com_v; phase 1: subtract the common velocity
