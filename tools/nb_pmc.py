@@ -7,6 +7,8 @@ from mdx import synth, engine as eng
 s = synth.pseudo_complex(d=12.5)
 tc = ["Protein", "Non-Protein"]
 e = eng.Engine(s, rc=1.0, dt=0.0005, nstlist=20, nstcalcenergy=0, tc_groups=tc, ref_t=[300, 300], tau_t=[0.02, 0.02], nsttcouple=2, rlist=1.095)
+for kv in filter(None, os.environ.get("MDX_DEBUG", "").split(",")):     # diagnostic switches "key=value,..."
+    k, v = kv.split("="); e.debug_set(int(k), int(v, 0))
 e.step(200); e.synchronize()
 print("rlist", e.rlist, e.list_stats())
 print(e.debug_time_nonbonded(False, 20))
