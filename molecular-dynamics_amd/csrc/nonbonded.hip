@@ -50,6 +50,17 @@ __device__ __forceinline__ float dpp_quad_x1(float v) { return __int_as_float(__
 __device__ __forceinline__ float dpp_quad_x2(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)); }
 __device__ __forceinline__ float dpp_half_mirror(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)); }
 __device__ __forceinline__ float dpp_row_ror8(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, true)); }
+__device__ __forceinline__ float dpp_row_shl4(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104, 0xF, 0xF, true)); }
+// Three values summed over the 8 lanes of a group in 8 instructions instead of 3 x 3 + a select: after the first exchange
+// a lane keeps x or y (lane bit 0), after the second x, y or z (bit 1), so lanes 0, 1, 2 of the group end with the sums of
+// x, y, z (b0, b1: the lane's bits 0 and 1).
+__device__ __forceinline__ float sum8_xyz(float x, float y, float z, bool b0, bool b1)
+{
+    const float a = (b0 ? y : x) + dpp_quad_x1(b0 ? x : y);
+    const float zz = z + dpp_quad_x1(z);
+    const float r = (b1 ? zz : a) + dpp_quad_x2(b1 ? a : zz);
+    return r + dpp_row_shl4(r);
+}
 __device__ __forceinline__ float sum8(float v)
 {
     v += dpp_quad_x1(v);
@@ -334,10 +345,11 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
             // the atomics to reach the L2, once per entry.
             asm volatile("" :: "v"(N.pj.x), "v"(N.pj.y), "v"(N.pj.z), "v"(N.pj.w), "v"(N.lj.x), "v"(N.lj.y), "v"(N.ex));
             // an entry none of whose tiles had a pair inside the cutoff has no j-force to reduce or add
-            if (did && !(ABL & 2)) { fjx = sum8(fjx); fjy = sum8(fjy); fjz = sum8(fjz); }
+            float fj3 = 0.0f;
+            if (did && !(ABL & 2)) fj3 = sum8_xyz(fjx, fjy, fjz, (ti & 1) != 0, (ti & 2) != 0);
             // (one 24-lane atomic per entry: pairing two entries into one 48-lane atomic costs more VALU instructions in
             // the selects than the second atomic costs now that no wait sits behind it)
-            if (did && ti < 3 && !((ABL & 64) && (A.dbg & 0x20000))) atomicAdd(at32(A.f_s, (unsigned)(3 * (cj * 8 + tj) + ti)), (ti == 0) ? fjx : ((ti == 1) ? fjy : fjz));
+            if (did && ti < 3 && !((ABL & 64) && (A.dbg & 0x20000))) atomicAdd(at32(A.f_s, (unsigned)(3 * (cj * 8 + tj) + ti)), fj3);
         };
         JSet Ja, Jb;
         fetch(Ja, 0);
@@ -352,11 +364,14 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
 #pragma unroll
         for (int c = 0; c < NI; c++) {
             float ax = fix[c], ay = fiy[c], az = fiz[c];
-            ax += dpp_row_ror8(ax); ay += dpp_row_ror8(ay); az += dpp_row_ror8(az);
-            ax += __shfl_xor(ax, 16, 64); ay += __shfl_xor(ay, 16, 64); az += __shfl_xor(az, 16, 64);
-            ax += __shfl_xor(ax, 32, 64); ay += __shfl_xor(ay, 32, 64); az += __shfl_xor(az, 32, 64);
+            // (x, y, z over the eight j-lanes of an i-atom with the same keep-one-give-one exchanges as sum8_xyz: the lanes
+            // with tj = 0, 1, 2 end with the sums of x, y, z)
+            const bool t0 = (tj & 1) != 0, t1 = (tj & 2) != 0;
+            const float a_ = (t0 ? ay : ax) + dpp_row_ror8(t0 ? ax : ay);
+            const float z_ = az + dpp_row_ror8(az);
+            float val = (t1 ? z_ : a_) + __shfl_xor(t1 ? a_ : z_, 16, 64);
+            val += __shfl_xor(val, 32, 64);
             if (tj < 3 && !((ABL & 64) && (A.dbg & 0x40000))) {
-                const float val = (tj == 0) ? ax : ((tj == 1) ? ay : az);
                 atomicAdd(at32(A.f_s, (unsigned)(3 * ((sci * 8 + c0 + c) * 8 + ti) + tj)), val);
             }
         }
