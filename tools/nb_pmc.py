@@ -11,4 +11,4 @@ for kv in filter(None, os.environ.get("MDX_DEBUG", "").split(",")):     # diagno
     k, v = kv.split("="); e.debug_set(int(k), int(v, 0))
 e.step(200); e.synchronize()
 print("rlist", e.rlist, e.list_stats())
-print(e.debug_time_nonbonded(False, 20))
+print(e.debug_time_nonbonded(bool(os.environ.get("MDX_NB_ENERGY")), 20))      # MDX_NB_ENERGY=1: the energy kernel
