@@ -178,8 +178,8 @@ def main():
     ap.add_argument("--ring", type=int, default=8, help="pinned trajectory-frame slots between the GPU and the encoder threads")
     ap.add_argument("--encoders", type=int, default=2, help="frames compressed at the same time (host threads)")
     ap.add_argument("--encoder-threads", type=int, default=0,
-                    help="threads that share the compression of one frame (segments); 0: 8 for one rank (they keep the drain of the "
-                         "last frame, which a short timed window sees in full, at 0.4 ms), 4 per rank when several ranks share the host")
+                    help="threads that share the compression of one frame (segments); 0: 12 for one rank (they keep the drain of the "
+                         "last frame, which a short timed window sees in full, at 0.2 ms), 4 per rank when several ranks share the host")
     ap.add_argument("--prime-steps", type=int, default=40,
                     help="un-timed steps before the warmup that run every kernel variant, one pair search, the coupling steps and the "
                          "frame pipeline once (first launches and first frames carry one-off costs of milliseconds)")
@@ -197,7 +197,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local)
     if args.encoder_threads <= 0:
-        args.encoder_threads = 8 if world == 1 else 4
+        args.encoder_threads = 12 if world == 1 else 4
     use_dist = world > 1 or bool(os.environ.get("MDX_BENCH_FORCE_DIST"))     # the latter: rehearsal of the N>1 code path on one GPU
     if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -275,8 +275,11 @@ def main():
     t_enq = time.perf_counter()
     e.synchronize(); torch.cuda.synchronize()
     t_gpu = time.perf_counter()
+    pending = pipe.pending() if pipe is not None else 0
+    t_fin = t_gpu
     if pipe is not None:
         pipe.finish()
+        t_fin = time.perf_counter()
         xtc.close()
     if use_dist:
         dist.barrier()
@@ -284,7 +287,11 @@ def main():
     # where the wall time of the timed region went on this rank: enqueueing the steps (the host runs ahead of the GPU),
     # the GPU finishing what was enqueued, the encoder threads finishing the frames still in flight
     phases = {"enqueue_ms": round((t_enq - t0) * 1e3, 3), "gpu_drain_ms": round((t_gpu - t_enq) * 1e3, 3),
-              "output_drain_ms": round((time.perf_counter() - t_gpu) * 1e3, 3)}
+              "output_drain_ms": round((time.perf_counter() - t_gpu) * 1e3, 3),
+              "frames_pending_when_gpu_done": pending, "encoders_finish_ms": round((t_fin - t_gpu) * 1e3, 3)}
+    if pipe is not None and pipe.stats["frames"]:
+        nf = pipe.stats["frames"]
+        phases["per_frame_ms"] = {k[:-2]: round(v / nf * 1e3, 3) for k, v in pipe.stats.items() if k.endswith("_s")}
     xtc_frames = xtc.frames if xtc is not None else 0
     xtc_bytes = os.path.getsize(xtc_path) if xtc_path else 0
     if pipe is not None and pipe.error is not None:

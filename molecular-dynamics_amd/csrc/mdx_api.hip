@@ -147,7 +147,7 @@ extern "C" void mdx_destroy(mdx_system *s)
                      s->col_count, s->col_astart, s->col_scstart, s->col_atoms, s->atom_col, s->atom_slot, s->wrapped, s->cj, s->work, s->work_order, s->sc_nwork,
                      s->exclmask, s->shift_ijk, s->shiftvec, s->bond_ij, s->bond_p, s->angle_ijk, s->angle_p, s->dih_ijkl, s->dih_p,
                      s->pair_ij, s->pair_p, s->posres_idx, s->posres_ref, s->posres_k, s->settle_idx, s->cons_ij, s->cons_len,
-                     s->comp_start, s->d_tc, s->pull_idx[0], s->pull_idx[1], s->gtab, s->htab, s->dd_q0, s->dd_invm0, s->dd_lj0, s->d };
+                     s->comp_start, s->comp_atom_start, s->comp_atoms, s->comp_local, s->free_atoms, s->d_tc, s->pull_idx[0], s->pull_idx[1], s->gtab, s->htab, s->dd_q0, s->dd_invm0, s->dd_lj0, s->d };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (s->h) (void)hipHostFree(s->h);
     if (s->ener_log) (void)hipHostFree(s->ener_log);
@@ -333,6 +333,7 @@ extern "C" int mdx_set_settles(mdx_system *s, int n, const int *idx, float doh, 
     std::vector<int4> t(n);
     for (int a = 0; a < n; a++) t[a] = make_int4(idx[3 * a], idx[3 * a + 1], idx[3 * a + 2], 0);
     s->nsettle = n; s->nsettle_cap = n; s->settle_doh = doh; s->settle_dhh = dhh;
+    s->h_settle.assign(idx, idx + 3 * (size_t)n); s->fused_plan = 0;
     return dev_upload(s, &s->settle_idx, t);
 }
 
@@ -377,6 +378,7 @@ extern "C" int mdx_set_constraints(mdx_system *s, int n, const int *idx, const f
             return MDX_ERR_UNSUPPORTED;
         }
     s->ncons = n; s->ncomp = n ? (int)cstart.size() - 1 : 0; s->lincs_order = order; s->lincs_iter = iter;
+    s->h_cij = cij; s->h_cstart = cstart; s->fused_plan = 0;
     s->ncomp_small = 0;
     for (int c = 0; c < s->ncomp; c++) if (cstart[c + 1] - cstart[c] <= 4) s->ncomp_small = c + 1;
     rc = dev_upload(s, &s->cons_ij, cij); if (rc) return rc;
@@ -841,7 +843,7 @@ extern "C" int mdx_get_kernel_timing(mdx_system *s, double *ms, long long *launc
 // spreading and the short-range kernels and records ev_spread behind the spreading; the caller then sums the
 // charge grids of all domains; phase 2 enqueues the rest of the PME chain, the join, the update and the
 // coupling kernels. Phase 0 is the whole step. `more` tells that another step follows in the same call.
-static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early)
+static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, bool &prepared)
 {
     int rc;
     const long long step = s->step;
@@ -863,7 +865,10 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early)
         if (do_search) if ((rc = mdx_search(s))) return rc;
         // the side streams start when the prepare kernel completes (its completion signal is the fork event:
         // an event recorded by a separate marker costs the main stream several microseconds)
-        if ((rc = mdx_launch_prepare(s, !forked_early))) return rc;
+        // (a fused update of the previous step in this call has already left the sorted coordinates of this one)
+        if (prepared) { if (!forked_early) if ((rc = mdx_fork(s))) return rc; }
+        else if ((rc = mdx_launch_prepare(s, !forked_early))) return rc;
+        prepared = false;
         // the nonbonded kernel is the critical path: enqueue it first, the side streams fill in
         const bool spread_main = s->spread_on_main != 0 && phase == 0;
         if (spread_main) if ((rc = mdx_launch_pme_spread(s, s->stream, true))) return rc;
@@ -898,7 +903,6 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early)
         s->pme_signalled = false;
         std::swap(s->stream, s->st_pme);
     } else if ((rc = mdx_join(s))) return rc;
-    if ((rc = mdx_launch_update(s, tc_apply, s->pcoupl == 2, need_vir))) return rc;
     // The PME and bonded kernels of the next step read only the new positions (the spread goes through the
     // sort permutation): when that step neither rebuilds the list nor accumulates energies they are
     // released here, ahead of the thermostat kernels and the coordinate sort, instead of by the prepare kernel.
@@ -907,7 +911,16 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early)
         const long long nx = step + 1;
         const bool vir_next = (s->nstcalcenergy > 0 && nx % s->nstcalcenergy == 0) || (s->pcoupl != 0 && nx % s->nstpcouple == 0);
         const bool search_next = s->steps_since_search + 1 >= s->nstlist;
-        if (phase == 0 && more && !vir_next && !search_next && !do_pc && s->early_fork) {
+        const bool fork_now = phase == 0 && more && !vir_next && !search_next && !do_pc && s->early_fork;
+        // Steps that accumulate no virial take leap-frog and constraints in one launch, which (when another step of this
+        // call follows on the same pair list and the cell stays as it is) also writes that step's sorted coordinates.
+        const bool fused = phase == 0 && !need_vir && !s->dd_on && s->fused_update && !s->rotate_streams && mdx_fused_plan(s) == 1;
+        if (fused) {
+            prepared = more && !search_next;
+            if ((rc = mdx_launch_update_fused(s, tc_apply, s->pcoupl == 2, prepared, fork_now && prepared))) return rc;
+            if (fork_now && prepared) forked_early = true;
+        } else if ((rc = mdx_launch_update(s, tc_apply, s->pcoupl == 2, need_vir))) return rc;
+        if (fork_now && !forked_early) {
             MDX_CHECK(s, hipEventRecord(s->ev_fork, s->stream));
             MDX_CHECK(s, hipStreamWaitEvent(s->st_pme, s->ev_fork, 0));
             MDX_CHECK(s, hipStreamWaitEvent(s->st_bond, s->ev_fork, 0));
@@ -947,15 +960,15 @@ extern "C" int mdx_step(mdx_system *s, long long nsteps)
         MDX_CHECK(s, hipStreamSynchronize(s->stream));
         s->pull_reset_pending = false;
     }
-    bool forked_early = false;
+    bool forked_early = false, prepared = false;
     for (long long it = 0; it < nsteps; it++)
-        if ((rc = step_phase(s, 0, it + 1 < nsteps, forked_early))) return rc;
+        if ((rc = step_phase(s, 0, it + 1 < nsteps, forked_early, prepared))) return rc;
     return MDX_OK;
 }
 
 // Domain decomposition: the two halves of a step around the summation of the charge grids (csrc/domdec.hip).
-int mdx_step_begin_internal(mdx_system *s) { bool fe = false; return step_phase(s, 1, false, fe); }
-int mdx_step_end_internal(mdx_system *s) { bool fe = false; return step_phase(s, 2, false, fe); }
+int mdx_step_begin_internal(mdx_system *s) { bool fe = false, pr = false; return step_phase(s, 1, false, fe, pr); }
+int mdx_step_end_internal(mdx_system *s) { bool fe = false, pr = false; return step_phase(s, 2, false, fe, pr); }
 
 extern "C" long long mdx_pop_energy_frames(mdx_system *s, double *out, long long max_frames)
 {

@@ -206,6 +206,11 @@ struct mdx_system {
     int ncons = 0; int ncomp = 0; int ncomp_small = 0;   // components are sorted by size; the first ncomp_small have <= 4 constraints
     int2 *cons_ij = nullptr; float *cons_len = nullptr; int *comp_start = nullptr;  // constraints sorted by component
     int lincs_order = 4, lincs_iter = 1;
+    // fused update (leap-frog + constraints + next step's sorted coordinates in one launch; update.hip)
+    std::vector<int> h_settle; std::vector<int2> h_cij; std::vector<int> h_cstart;   // host copies of the constraint topology
+    int fused_plan = 0;           // 0: not built yet, 1: usable, -1: this topology needs the separate kernels
+    int fused_update = 1;         // use it on steps without virial (mdx_debug_set key 12)
+    int *comp_atom_start = nullptr, *comp_atoms = nullptr, *comp_local = nullptr, *free_atoms = nullptr; int nfree = 0;
     // integration / coupling
     float dt = 0.002f;
     int ntc = 0; double ref_t[MDX_MAX_TC] = {0}, tau_t[MDX_MAX_TC] = {0}, ndf[MDX_MAX_TC] = {0};
@@ -277,6 +282,8 @@ int mdx_launch_bonded(mdx_system *s, bool energy, unsigned flags);
 int mdx_launch_pull(mdx_system *s, bool log_now, bool energy);
 int mdx_launch_update(mdx_system *s, bool do_tc, bool do_pr, bool virial);
 int mdx_launch_constrain(mdx_system *s, float inv_dt, bool virial, int lincs_iter);
+int mdx_fused_plan(mdx_system *s);
+int mdx_launch_update_fused(mdx_system *s, bool do_tc, bool do_pr, bool write_sorted, bool fork_signal);
 void mdx_frames_free(mdx_system *s);
 int mdx_launch_ke(mdx_system *s, bool old_slot, bool tensor, hipStream_t st = nullptr);
 int mdx_launch_comm_phase(mdx_system *s, int phase);

@@ -23,6 +23,9 @@
 #include <math.h>
 #include <vector>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
 
 extern "C" {
 
@@ -176,17 +179,65 @@ static uint32_t be32(const unsigned char *p) { return ((uint32_t)p[0] << 24) | (
 static float bef32(const unsigned char *p) { uint32_t u = be32(p); float f; memcpy(&f, &u, 4); return f; }
 
 }  // extern "C" (templates have C++ linkage)
-// fn(k) for k = 0 .. T-1, k = 0 on the calling thread and the others on threads started for the call (tens of
-// microseconds each, against milliseconds per frame; no pool whose idle workers would spin next to the step loop)
+// fn(k) for k = 0 .. T-1, k = 0 on the calling thread and the others on workers that belong to the calling thread and
+// sleep on a condition variable between calls (they never spin next to the step loop). Starting threads per call cost
+// 30-40 us each, one after the other: at a dozen slices and two calls per frame that was most of a millisecond of a
+// frame that is otherwise compressed in half of one.
+class SlicePool {
+    std::mutex m;
+    std::condition_variable cv, cv_done;
+    std::vector<std::thread> th;
+    const std::function<void(int)> *job = nullptr;
+    int T = 0, left = 0;
+    unsigned long long gen = 0;
+    bool stop = false;
+    void worker(int k)
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void(int)> *j = nullptr;
+            {
+                std::unique_lock<std::mutex> l(m);
+                cv.wait(l, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen;
+                if (k < T) j = job;
+            }
+            if (!j) continue;
+            (*j)(k);
+            std::lock_guard<std::mutex> l(m);
+            if (--left == 0) cv_done.notify_one();
+        }
+    }
+public:
+    void run(int nslices, const std::function<void(int)> &fn)
+    {
+        if (nslices <= 1) { fn(0); return; }
+        while ((int)th.size() < nslices - 1) { const int k = (int)th.size() + 1; th.emplace_back([this, k] { worker(k); }); }
+        {
+            std::lock_guard<std::mutex> l(m);
+            job = &fn; T = nslices; left = nslices - 1; gen++;
+        }
+        cv.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> l(m);
+        cv_done.wait(l, [&] { return left == 0; });
+        job = nullptr;
+    }
+    ~SlicePool()
+    {
+        { std::lock_guard<std::mutex> l(m); stop = true; }
+        cv.notify_all();
+        for (std::thread &t : th) t.join();
+    }
+};
 template <typename F>
 static void run_slices(int T, F fn)
 {
     if (T <= 1) { fn(0); return; }
-    std::vector<std::thread> th;
-    th.reserve(T - 1);
-    for (int k = 1; k < T; k++) th.emplace_back([&fn, k] { fn(k); });
-    fn(0);
-    for (std::thread &t : th) t.join();
+    static thread_local SlicePool pool;
+    const std::function<void(int)> f = [&fn](int k) { fn(k); };
+    pool.run(T, f);
 }
 extern "C" {
 

@@ -4,42 +4,54 @@
 // `lincs_order/iter`, `tcoupl = V-rescale`, `pcoupl`, `nstcomm` switch on in gmx mdrun
 // (/root/reference/mdp/production.mdp:3-5,16-19,31-40; npt_complex.mdp:64-66).
 #include "mdx_internal.h"
+#include <hip/hip_ext.h>
 #include <algorithm>
+#include <vector>
 
 // v' = lambda_g v + f/m dt - dt_pc M v  (lambda_g: V-rescale factor of the atom's group, drawn from the kinetic
 // energy of v itself, so it scales v and not the force kick; M: Parrinello-Rahman coupling matrix, held between
 // coupling steps and applied every step over dt_pc = dt); xp = x + v' dt.
 // Total force = original-order array + sorted nonbonded buffer.
-__global__ __launch_bounds__(256) void k_leapfrog(int n, const float4 *__restrict__ x, float4 *__restrict__ xp,
-                                                  float4 *__restrict__ v, float *__restrict__ f, const float *__restrict__ f_pme,
-                                                  const float *__restrict__ f_s, const int *__restrict__ sorted_of,
-                                                  const int *__restrict__ tcgrp, const DevState *__restrict__ d, float dt,
-                                                  int use_lambda, int use_pr, float dt_pc)
+struct LeapArgs {
+    float *f; const float *f_pme; float *f_s; const int *sorted_of; const int *tcgrp; const DevState *d;
+    float dt; int use_lambda, use_pr; float dt_pc; int clear_sorted;
+};
+// One atom: reads and clears its force entries (the sorted nonbonded buffer only with clear_sorted), returns the new
+// velocity (w: inverse mass), the unconstrained new position (w: charge) and the atom's slot in the cluster order.
+__device__ __forceinline__ void d_leap(const LeapArgs &L, const int i, const float4 xi, float4 &vi, float4 &xpo, int &g)
 {
-    MDX_STAMP(d, 11);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 xi = x[i];
-    float4 vi = v[i];
-    const int g = sorted_of[i];
-    const float fx = f[3 * i] + f_pme[3 * i] + f_s[3 * g], fy = f[3 * i + 1] + f_pme[3 * i + 1] + f_s[3 * g + 1],
-                fz = f[3 * i + 2] + f_pme[3 * i + 2] + f_s[3 * g + 2];
+    g = L.sorted_of[i];
+    const float fx = L.f[3 * i] + L.f_pme[3 * i] + L.f_s[3 * g], fy = L.f[3 * i + 1] + L.f_pme[3 * i + 1] + L.f_s[3 * g + 1],
+                fz = L.f[3 * i + 2] + L.f_pme[3 * i + 2] + L.f_s[3 * g + 2];
     // the accumulation buffer of the bonded-type kernels is consumed here: leave it cleared for the
     // next step instead of paying a separate fill on the critical path
-    f[3 * i] = 0.0f; f[3 * i + 1] = 0.0f; f[3 * i + 2] = 0.0f;
-    const float im = vi.w;
+    L.f[3 * i] = 0.0f; L.f[3 * i + 1] = 0.0f; L.f[3 * i + 2] = 0.0f;
+    if (L.clear_sorted) { L.f_s[3 * g] = 0.0f; L.f_s[3 * g + 1] = 0.0f; L.f_s[3 * g + 2] = 0.0f; }
+    const float im = vi.w, dt = L.dt;
     float lam = 1.0f;
-    if (use_lambda) lam = (float)d->lambda[tcgrp[i]];
+    if (L.use_lambda) lam = (float)L.d->lambda[L.tcgrp[i]];
     float nx = fmaf(lam, vi.x, fx * im * dt), ny = fmaf(lam, vi.y, fy * im * dt), nz = fmaf(lam, vi.z, fz * im * dt);
-    if (use_pr) {
-        const double *M = d->pr_M;
-        nx -= dt_pc * (float)(M[0] * vi.x + M[1] * vi.y + M[2] * vi.z);
-        ny -= dt_pc * (float)(M[3] * vi.x + M[4] * vi.y + M[5] * vi.z);
-        nz -= dt_pc * (float)(M[6] * vi.x + M[7] * vi.y + M[8] * vi.z);
+    if (L.use_pr) {
+        const double *M = L.d->pr_M;
+        nx -= L.dt_pc * (float)(M[0] * vi.x + M[1] * vi.y + M[2] * vi.z);
+        ny -= L.dt_pc * (float)(M[3] * vi.x + M[4] * vi.y + M[5] * vi.z);
+        nz -= L.dt_pc * (float)(M[6] * vi.x + M[7] * vi.y + M[8] * vi.z);
     }
     vi.x = nx; vi.y = ny; vi.z = nz;
+    xpo = make_float4(xi.x + nx * dt, xi.y + ny * dt, xi.z + nz * dt, xi.w);
+}
+
+__global__ __launch_bounds__(256) void k_leapfrog(int n, const float4 *__restrict__ x, float4 *__restrict__ xp,
+                                                  float4 *__restrict__ v, LeapArgs L)
+{
+    MDX_STAMP(L.d, 11);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 vi = v[i], xo;
+    int g;
+    d_leap(L, i, x[i], vi, xo, g);
     v[i] = vi;
-    xp[i] = make_float4(xi.x + nx * dt, xi.y + ny * dt, xi.z + nz * dt, xi.w);
+    xp[i] = xo;
 }
 
 // Rigid three-site water: solve the three holonomic constraint equations
@@ -48,6 +60,76 @@ __global__ __launch_bounds__(256) void k_leapfrog(int n, const float4 *__restric
 // is the same root, reached here iteratively in float32 with differences formed first).
 // One thread per molecule; also corrects velocities and, on virial steps, accumulates the
 // constraint virial -1/2 sum r_old (x) G with G = m dx / dt^2.
+// The solve: old positions o0, h10, h20, unconstrained new positions po, ph1, ph2, inverse masses -> displacements of
+// the three atoms, the multipliers and the old bond vectors (for the virial).
+__device__ __forceinline__ void settle_solve(const float3 o0, const float3 h10, const float3 h20, const float3 po, const float3 ph1,
+                                             const float3 ph2, const float imo, const float imh, const float doh, const float dhh,
+                                             float3 &dO, float3 &dH1, float3 &dH2, float *lam, float3 *r0)
+{
+    // old bond vectors (constraint gradients) and unconstrained new bond vectors
+    r0[0] = o0 - h10; r0[1] = o0 - h20; r0[2] = h10 - h20;
+    float3 s[3] = { po - ph1, po - ph2, ph1 - ph2 };
+    const float L2[3] = { doh * doh, doh * doh, dhh * dhh };
+    // d s_k / d lambda_m = A[k][m] * r0[m]
+    const float A[3][3] = { { imo + imh, imo, -imh }, { imo, imo + imh, imh }, { -imh, imh, 2.0f * imh } };
+    lam[0] = lam[1] = lam[2] = 0.0f;
+    for (int it = 0; it < 6; it++) {
+        float3 c[3];
+        float sig[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            c[k] = s[k] + (A[k][0] * lam[0]) * r0[0] + (A[k][1] * lam[1]) * r0[1] + (A[k][2] * lam[2]) * r0[2];
+            sig[k] = dot3(c[k], c[k]) - L2[k];
+        }
+        float J[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int m = 0; m < 3; m++) J[k][m] = 2.0f * A[k][m] * dot3(c[k], r0[m]);
+        // solve J dl = -sig (Cramer)
+        const float det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
+                          J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+        const float id = 1.0f / det;
+        const float b0 = -sig[0], b1 = -sig[1], b2 = -sig[2];
+        const float d0 = b0 * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (b1 * J[2][2] - J[1][2] * b2) + J[0][2] * (b1 * J[2][1] - J[1][1] * b2);
+        const float d1 = J[0][0] * (b1 * J[2][2] - J[1][2] * b2) - b0 * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) + J[0][2] * (J[1][0] * b2 - b1 * J[2][0]);
+        const float d2 = J[0][0] * (J[1][1] * b2 - b1 * J[2][1]) - J[0][1] * (J[1][0] * b2 - b1 * J[2][0]) + b0 * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+        lam[0] += d0 * id; lam[1] += d1 * id; lam[2] += d2 * id;
+        const float tol = 1e-7f * L2[2];
+        if (fabsf(sig[0]) < tol && fabsf(sig[1]) < tol && fabsf(sig[2]) < tol && it > 0) break;
+    }
+    // displacements: dO = imo (l0 r0 + l1 r1), dH1 = imh (-l0 r0 + l2 r2), dH2 = imh (-l1 r1 - l2 r2)
+    dO = imo * (lam[0] * r0[0] + lam[1] * r0[1]);
+    dH1 = imh * (lam[2] * r0[2] - lam[0] * r0[0]);
+    dH2 = -imh * (lam[1] * r0[1] + lam[2] * r0[2]);
+}
+
+template <bool VIRIAL>
+__device__ __forceinline__ void settle_core(const float3 o0, const float3 h10, const float3 h20, float4 &po, float4 &ph1, float4 &ph2,
+                                            float4 &vo, float4 &vh1, float4 &vh2, float doh, float dhh, float inv_dt, float *v9)
+{
+    float3 dO, dH1, dH2, r0[3];
+    float lam[3];
+    settle_solve(o0, h10, h20, xyz(po), xyz(ph1), xyz(ph2), vo.w, vh1.w, doh, dhh, dO, dH1, dH2, lam, r0);
+    po = make_float4(po.x + dO.x, po.y + dO.y, po.z + dO.z, po.w);
+    ph1 = make_float4(ph1.x + dH1.x, ph1.y + dH1.y, ph1.z + dH1.z, ph1.w);
+    ph2 = make_float4(ph2.x + dH2.x, ph2.y + dH2.y, ph2.z + dH2.z, ph2.w);
+    vo = make_float4(vo.x + dO.x * inv_dt, vo.y + dO.y * inv_dt, vo.z + dO.z * inv_dt, vo.w);
+    vh1 = make_float4(vh1.x + dH1.x * inv_dt, vh1.y + dH1.y * inv_dt, vh1.z + dH1.z * inv_dt, vh1.w);
+    vh2 = make_float4(vh2.x + dH2.x * inv_dt, vh2.y + dH2.y * inv_dt, vh2.z + dH2.z * inv_dt, vh2.w);
+    if (VIRIAL) {
+        // constraint forces along the old bonds: G_k = lam_k r0_k / dt^2 acting on the first atom
+        const float s2 = inv_dt * inv_dt;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float3 g = (lam[k] * s2) * r0[k];
+            v9[0] += r0[k].x * g.x; v9[1] += r0[k].x * g.y; v9[2] += r0[k].x * g.z;
+            v9[3] += r0[k].y * g.x; v9[4] += r0[k].y * g.y; v9[5] += r0[k].y * g.z;
+            v9[6] += r0[k].z * g.x; v9[7] += r0[k].z * g.y; v9[8] += r0[k].z * g.z;
+        }
+    }
+}
+
 template <bool VIRIAL>
 __device__ __forceinline__ void d_settle(const int t, int nw, const int4 *__restrict__ idx, const float4 *__restrict__ x,
                                          float4 *__restrict__ xp, float4 *__restrict__ v, float doh, float dhh,
@@ -56,63 +138,11 @@ __device__ __forceinline__ void d_settle(const int t, int nw, const int4 *__rest
     float v9[9] = { 0 };
     if (t < nw) {
         const int4 a = idx[t];
-        const float4 vo = v[a.x], vh1 = v[a.y], vh2 = v[a.z];
-        const float imo = vo.w, imh = vh1.w;
-        const float3 o0 = xyz(x[a.x]), h10 = xyz(x[a.y]), h20 = xyz(x[a.z]);
-        const float4 po = xp[a.x], ph1 = xp[a.y], ph2 = xp[a.z];
-        // old bond vectors (constraint gradients) and unconstrained new bond vectors
-        const float3 r0[3] = { o0 - h10, o0 - h20, h10 - h20 };
-        float3 s[3] = { xyz(po) - xyz(ph1), xyz(po) - xyz(ph2), xyz(ph1) - xyz(ph2) };
-        const float L2[3] = { doh * doh, doh * doh, dhh * dhh };
-        // d s_k / d lambda_m = A[k][m] * r0[m]
-        const float A[3][3] = { { imo + imh, imo, -imh }, { imo, imo + imh, imh }, { -imh, imh, 2.0f * imh } };
-        float lam[3] = { 0.0f, 0.0f, 0.0f };
-        for (int it = 0; it < 6; it++) {
-            float3 c[3];
-            float sig[3];
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                c[k] = s[k] + (A[k][0] * lam[0]) * r0[0] + (A[k][1] * lam[1]) * r0[1] + (A[k][2] * lam[2]) * r0[2];
-                sig[k] = dot3(c[k], c[k]) - L2[k];
-            }
-            float J[3][3];
-#pragma unroll
-            for (int k = 0; k < 3; k++)
-#pragma unroll
-                for (int m = 0; m < 3; m++) J[k][m] = 2.0f * A[k][m] * dot3(c[k], r0[m]);
-            // solve J dl = -sig (Cramer)
-            const float det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
-                              J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
-            const float id = 1.0f / det;
-            const float b0 = -sig[0], b1 = -sig[1], b2 = -sig[2];
-            const float d0 = b0 * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (b1 * J[2][2] - J[1][2] * b2) + J[0][2] * (b1 * J[2][1] - J[1][1] * b2);
-            const float d1 = J[0][0] * (b1 * J[2][2] - J[1][2] * b2) - b0 * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) + J[0][2] * (J[1][0] * b2 - b1 * J[2][0]);
-            const float d2 = J[0][0] * (J[1][1] * b2 - b1 * J[2][1]) - J[0][1] * (J[1][0] * b2 - b1 * J[2][0]) + b0 * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
-            lam[0] += d0 * id; lam[1] += d1 * id; lam[2] += d2 * id;
-            const float tol = 1e-7f * L2[2];
-            if (fabsf(sig[0]) < tol && fabsf(sig[1]) < tol && fabsf(sig[2]) < tol && it > 0) break;
-        }
-        // displacements: dO = imo (l0 r0 + l1 r1), dH1 = imh (-l0 r0 + l2 r2), dH2 = imh (-l1 r1 - l2 r2)
-        const float3 dO = imo * (lam[0] * r0[0] + lam[1] * r0[1]);
-        const float3 dH1 = imh * (lam[2] * r0[2] - lam[0] * r0[0]);
-        const float3 dH2 = -imh * (lam[1] * r0[1] + lam[2] * r0[2]);
-        xp[a.x] = make_float4(po.x + dO.x, po.y + dO.y, po.z + dO.z, po.w);
-        xp[a.y] = make_float4(ph1.x + dH1.x, ph1.y + dH1.y, ph1.z + dH1.z, ph1.w);
-        xp[a.z] = make_float4(ph2.x + dH2.x, ph2.y + dH2.y, ph2.z + dH2.z, ph2.w);
-        v[a.x] = make_float4(vo.x + dO.x * inv_dt, vo.y + dO.y * inv_dt, vo.z + dO.z * inv_dt, vo.w);
-        v[a.y] = make_float4(vh1.x + dH1.x * inv_dt, vh1.y + dH1.y * inv_dt, vh1.z + dH1.z * inv_dt, vh1.w);
-        v[a.z] = make_float4(vh2.x + dH2.x * inv_dt, vh2.y + dH2.y * inv_dt, vh2.z + dH2.z * inv_dt, vh2.w);
-        if (VIRIAL) {
-            // constraint forces along the old bonds: G_k = lam_k r0_k / dt^2 acting on the first atom
-            const float s2 = inv_dt * inv_dt;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const float3 g = (lam[k] * s2) * r0[k];
-                v9[0] += r0[k].x * g.x; v9[1] += r0[k].x * g.y; v9[2] += r0[k].x * g.z;
-                v9[3] += r0[k].y * g.x; v9[4] += r0[k].y * g.y; v9[5] += r0[k].y * g.z;
-                v9[6] += r0[k].z * g.x; v9[7] += r0[k].z * g.y; v9[8] += r0[k].z * g.z;
-            }
-        }
+        float4 vo = v[a.x], vh1 = v[a.y], vh2 = v[a.z];
+        float4 po = xp[a.x], ph1 = xp[a.y], ph2 = xp[a.z];
+        settle_core<VIRIAL>(xyz(x[a.x]), xyz(x[a.y]), xyz(x[a.z]), po, ph1, ph2, vo, vh1, vh2, doh, dhh, inv_dt, v9);
+        xp[a.x] = po; xp[a.y] = ph1; xp[a.z] = ph2;
+        v[a.x] = vo; v[a.y] = vh1; v[a.z] = vh2;
     }
     if (VIRIAL) {
         __shared__ double red[16];
@@ -254,6 +284,186 @@ __global__ __launch_bounds__(128) void k_constrain(ConstrainArgs A)
     else
         d_lincs<VIRIAL, MDX_LINCS_MAXK>(A.ncomp_small + (b - A.nbw - A.nb4) * 128 + threadIdx.x, A.ncomp_small, A.ncomp - A.ncomp_small,
                                         A.comp_start, A.cij, A.clen, A.x, A.xp, A.v, A.order, A.niter, A.inv_dt, A.dw);
+}
+
+// Leap-frog, constraints and the next step's sorted coordinates in one launch, for the steps that accumulate no virial.
+// Every atom is advanced by the thread that constrains it: a water by its SETTLE thread (positions and velocities stay
+// in registers between the two), the atoms of a LINCS component by the component's thread, all other atoms by threads
+// of a fourth range. With write_sorted the thread also refreshes its atoms' entries of the cluster-ordered coordinate
+// array, clears their slots of the sorted force buffer and block 0 resets the unit queues of the nonbonded kernel: the
+// next step then needs no prepare launch (filler slots keep the position they had at the pair search; they carry no
+// charge and no LJ well, so where they sit inside their cluster's bounds does not matter).
+struct FusedArgs {
+    ConstrainArgs C;
+    LeapArgs L;
+    int nbw3;                   // workgroups of the water range: 42 waters each (three lanes per water)
+    int nbfree, nfree; const int *free_atoms;
+    const int *comp_atom_start; const int *comp_atoms;
+    const int2 *comp_local;     // per constraint: positions of its two atoms in the component's atom list
+    int write_sorted; const int *shift_s; float4 *xq_s;
+};
+__device__ __forceinline__ void d_sorted_write(const FusedArgs &A, const int g, const float4 p)
+{
+    const float *h = A.C.dw->box.h;
+    int sa, sb, sc;
+    unpack_shift(A.shift_s[g], sa, sb, sc);
+    float4 o;
+    o.x = p.x + sa * h[0] + sb * h[3] + sc * h[6];
+    o.y = p.y + sb * h[4] + sc * h[7];
+    o.z = p.z + sc * h[8];
+    o.w = p.w;
+    A.xq_s[g] = o;
+}
+// A constraint component in the fused update: its thread advances the component's atoms, keeps their new positions and
+// velocities in a private column of LDS (slot k of atom k of the component's atom list; `nthr` columns side by side, so
+// neighbouring threads use neighbouring banks), runs LINCS on those and stores every atom once. The separate LINCS
+// kernel updates positions and velocities in global memory constraint by constraint, and every such read-modify-write
+// waits a memory round trip for the one before it (an atom shared by two constraints): about 10 us per launch, which
+// in a fused kernel would sit behind the leap-frog of the same thread.
+template <int MAXK>
+__device__ __forceinline__ void d_fused_lincs(const FusedArgs &A, const int t, const int comp0, const int ncomp, float *sh,
+                                              const int tid, const int nthr)
+{
+    constexpr int NA = MAXK + 1;
+    const ConstrainArgs &C = A.C;
+    if (t >= comp0 + ncomp) return;
+    auto S = [&](int slot, int c) -> float & { return sh[(slot * 7 + c) * nthr + tid]; };
+    const int a0 = A.comp_atom_start[t], na = A.comp_atom_start[t + 1] - a0;
+    int ai[NA], gi[NA];
+    float qa[NA];
+#pragma unroll
+    for (int k = 0; k < NA; k++) {
+        ai[k] = 0; gi[k] = 0; qa[k] = 0.0f;
+        if (k < na) {
+            const int i = A.comp_atoms[a0 + k];
+            float4 vi = C.v[i], xo;
+            d_leap(A.L, i, C.x[i], vi, xo, gi[k]);
+            ai[k] = i; qa[k] = xo.w;
+            S(k, 0) = xo.x; S(k, 1) = xo.y; S(k, 2) = xo.z; S(k, 3) = vi.x; S(k, 4) = vi.y; S(k, 5) = vi.z; S(k, 6) = vi.w;
+        }
+    }
+    const int c0 = C.comp_start[t];
+    const int K = C.comp_start[t + 1] - c0;
+    int la[MAXK], lb[MAXK];
+    float3 B[MAXK];
+    float Sd[MAXK], len[MAXK], rhs[MAXK], sol[MAXK], tmp[MAXK], ima[MAXK], imb[MAXK];
+    float Acoef[MAXK][MAXK];
+    LINCS_FOR(k) {
+        const int2 p = C.cij[c0 + k];
+        const int2 q = A.comp_local[c0 + k];
+        la[k] = q.x; lb[k] = q.y; len[k] = C.clen[c0 + k];
+        ima[k] = S(q.x, 6); imb[k] = S(q.y, 6);
+        Sd[k] = rsqrtf(ima[k] + imb[k]);
+        const float3 d = xyz(C.x[p.x]) - xyz(C.x[p.y]);
+        B[k] = rsqrtf(dot3(d, d)) * d;
+    }
+    LINCS_FOR(k)
+        LINCS_FOR(m) {
+            float c = 0.0f;
+            if (m != k) {
+                // sign +1 when the shared atom is first in both or second in both
+                if (la[k] == la[m]) c = -ima[k];
+                else if (lb[k] == lb[m]) c = -imb[k];
+                else if (la[k] == lb[m]) c = ima[k];
+                else if (lb[k] == la[m]) c = imb[k];
+                c *= Sd[k] * Sd[m] * dot3(B[k], B[m]);
+            }
+            Acoef[k][m] = c;
+        }
+    for (int pass = 0; pass <= C.niter; pass++) {
+        LINCS_FOR(k) {
+            const float3 d = make_float3(S(la[k], 0) - S(lb[k], 0), S(la[k], 1) - S(lb[k], 1), S(la[k], 2) - S(lb[k], 2));
+            if (pass == 0) rhs[k] = Sd[k] * (dot3(B[k], d) - len[k]);
+            else {
+                const float p2 = 2.0f * len[k] * len[k] - dot3(d, d);
+                rhs[k] = Sd[k] * (len[k] - sqrtf(fmaxf(p2, 0.0f)));
+            }
+            sol[k] = rhs[k];
+        }
+        for (int o = 0; o < C.order; o++) {
+            LINCS_FOR(k) {
+                float a = 0.0f;
+                LINCS_FOR(m) a += Acoef[k][m] * rhs[m];
+                tmp[k] = a;
+            }
+            LINCS_FOR(k) { rhs[k] = tmp[k]; sol[k] += tmp[k]; }
+        }
+        LINCS_FOR(k) {
+            const float l = Sd[k] * sol[k];
+            const float3 da = (-ima[k] * l) * B[k], db = (imb[k] * l) * B[k];
+            S(la[k], 0) += da.x; S(la[k], 1) += da.y; S(la[k], 2) += da.z;
+            S(lb[k], 0) += db.x; S(lb[k], 1) += db.y; S(lb[k], 2) += db.z;
+            S(la[k], 3) += da.x * C.inv_dt; S(la[k], 4) += da.y * C.inv_dt; S(la[k], 5) += da.z * C.inv_dt;
+            S(lb[k], 3) += db.x * C.inv_dt; S(lb[k], 4) += db.y * C.inv_dt; S(lb[k], 5) += db.z * C.inv_dt;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NA; k++)
+        if (k < na) {
+            const float4 xo = make_float4(S(k, 0), S(k, 1), S(k, 2), qa[k]);
+            C.xp[ai[k]] = xo;
+            C.v[ai[k]] = make_float4(S(k, 3), S(k, 4), S(k, 5), S(k, 6));
+            if (A.write_sorted) d_sorted_write(A, gi[k], xo);
+        }
+}
+#define MDX_FUSED_LARGE_THREADS 32      // threads of a workgroup that take a component of more than 4 constraints (LDS columns of 17 atoms)
+__global__ __launch_bounds__(128) void k_update_fused(FusedArgs A)
+{
+    MDX_STAMP(A.C.dw, 11);
+    __shared__ float sh[5 * 7 * 128];       // LINCS ranges: 5 atoms x 7 values x 128 threads, or 17 x 7 x 32
+    static_assert((MDX_LINCS_MAXK + 1) * 7 * MDX_FUSED_LARGE_THREADS <= 5 * 7 * 128, "LDS columns of the large components");
+    const ConstrainArgs &C = A.C;
+    const int b = blockIdx.x;
+    if (A.write_sorted && b == 0 && threadIdx.x < 8) C.dw->nb_head[threadIdx.x * 32] = 0;
+    if (b < A.nbw3) {
+        // One lane per atom, three consecutive lanes per water (21 waters per wave, the last lane idles): the leap-frog of
+        // an atom is its lane's, the three lanes exchange old and new positions and each solves the water's constraints
+        // for its own atom (lanes are cheaper than the latency of one thread walking through three atoms).
+        const int lane = threadIdx.x & 63, role = lane % 3;
+        const int w = (b * 2 + (threadIdx.x >> 6)) * 21 + lane / 3;
+        const bool valid = lane < 63 && w < C.nw;
+        int i = 0, g = 0;
+        float4 xi = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vi = xi, xpo = xi;
+        if (valid) {
+            const int4 a = C.settle_idx[w];
+            i = role == 0 ? a.x : (role == 1 ? a.y : a.z);
+            xi = C.x[i]; vi = C.v[i];
+            d_leap(A.L, i, xi, vi, xpo, g);
+        }
+        const int base = lane - role;
+        float3 xo[3], xn[3];
+        float im[2];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const int src = min(base + r, 63);
+            xo[r] = make_float3(__shfl(xi.x, src, 64), __shfl(xi.y, src, 64), __shfl(xi.z, src, 64));
+            xn[r] = make_float3(__shfl(xpo.x, src, 64), __shfl(xpo.y, src, 64), __shfl(xpo.z, src, 64));
+            if (r < 2) im[r] = __shfl(vi.w, src, 64);
+        }
+        if (!valid) return;
+        float3 dO, dH1, dH2, r0[3];
+        float lam[3];
+        settle_solve(xo[0], xo[1], xo[2], xn[0], xn[1], xn[2], im[0], im[1], C.doh, C.dhh, dO, dH1, dH2, lam, r0);
+        const float3 dd = role == 0 ? dO : (role == 1 ? dH1 : dH2);
+        xpo = make_float4(xpo.x + dd.x, xpo.y + dd.y, xpo.z + dd.z, xpo.w);
+        vi = make_float4(vi.x + dd.x * C.inv_dt, vi.y + dd.y * C.inv_dt, vi.z + dd.z * C.inv_dt, vi.w);
+        C.xp[i] = xpo; C.v[i] = vi;
+        if (A.write_sorted) d_sorted_write(A, g, xpo);
+    } else if (b < A.nbw3 + C.nb4) {
+        d_fused_lincs<4>(A, (b - A.nbw3) * 128 + threadIdx.x, 0, C.ncomp_small, sh, threadIdx.x, 128);
+    } else if (b < A.nbw3 + C.nb4 + A.nbfree) {
+        const int t = (b - A.nbw3 - C.nb4) * 128 + threadIdx.x;
+        if (t >= A.nfree) return;
+        const int i = A.free_atoms[t];
+        float4 vi = C.v[i], xo; int g;
+        d_leap(A.L, i, C.x[i], vi, xo, g);
+        C.v[i] = vi; C.xp[i] = xo;
+        if (A.write_sorted) d_sorted_write(A, g, xo);
+    } else {
+        if (threadIdx.x < MDX_FUSED_LARGE_THREADS)
+            d_fused_lincs<MDX_LINCS_MAXK>(A, C.ncomp_small + (b - A.nbw3 - C.nb4 - A.nbfree) * MDX_FUSED_LARGE_THREADS + threadIdx.x, C.ncomp_small,
+                                          C.ncomp - C.ncomp_small, sh, threadIdx.x, MDX_FUSED_LARGE_THREADS);
+    }
 }
 
 // Half-step kinetic energy per T-coupling group (+ tensor) from the current velocities.
@@ -516,14 +726,98 @@ __global__ void k_merge_forces(int n, const float *__restrict__ f, const float *
     out[3 * i] = a; out[3 * i + 1] = b; out[3 * i + 2] = c;
 }
 
+static LeapArgs leap_args(mdx_system *s, bool do_tc, bool do_pr, bool clear_sorted)
+{
+    LeapArgs L;
+    L.f = s->f; L.f_pme = s->f_pme; L.f_s = s->f_s; L.sorted_of = s->sorted_of; L.tcgrp = s->tcgrp; L.d = s->d;
+    L.dt = s->dt; L.use_lambda = do_tc ? 1 : 0; L.use_pr = do_pr ? 1 : 0; L.dt_pc = s->dt; L.clear_sorted = clear_sorted ? 1 : 0;
+    return L;
+}
+
 int mdx_launch_update(mdx_system *s, bool do_tc, bool do_pr, bool virial)
 {
     const int nb = (s->n + 255) / 256;
-    hipLaunchKernelGGL(k_leapfrog, dim3(nb), dim3(256), 0, s->stream, s->n, s->x, s->xp, s->v, s->f, s->f_pme, s->f_s, s->sorted_of,
-                       s->tcgrp, s->d, s->dt, do_tc ? 1 : 0, do_pr ? 1 : 0, s->dt);
+    hipLaunchKernelGGL(k_leapfrog, dim3(nb), dim3(256), 0, s->stream, s->n, (const float4 *)s->x, s->xp, s->v, leap_args(s, do_tc, do_pr, false));
     int rc = mdx_launch_constrain(s, 1.0f / s->dt, virial, s->lincs_iter);
     if (rc) return rc;
     // the constrained new positions become the state
+    float4 *t = s->x; s->x = s->xp; s->xp = t;
+    return MDX_OK;
+}
+
+static void constrain_args(mdx_system *s, ConstrainArgs &A, float inv_dt, int lincs_iter)
+{
+    A.nbw = (s->nsettle + 127) / 128; A.nb4 = (s->ncomp_small + 127) / 128;
+    A.nw = s->nsettle; A.settle_idx = s->settle_idx; A.doh = s->settle_doh; A.dhh = s->settle_dhh;
+    A.ncomp_small = s->ncomp_small; A.ncomp = s->ncomp; A.comp_start = s->comp_start; A.cij = s->cons_ij; A.clen = s->cons_len;
+    A.order = s->lincs_order; A.niter = lincs_iter; A.x = s->x; A.xp = s->xp; A.v = s->v; A.inv_dt = inv_dt; A.dw = s->d;
+}
+
+// Which thread advances which atom in the fused update: every atom must belong to exactly one water, one constraint
+// component or to neither. Builds the per-component atom lists and the list of unconstrained atoms; 1: usable.
+int mdx_fused_plan(mdx_system *s)
+{
+    if (s->fused_plan != 0) return s->fused_plan;
+    s->fused_plan = -1;
+    if (s->dd_on || s->nsettle != s->nsettle_cap || (int)s->h_settle.size() != 3 * s->nsettle) return s->fused_plan;
+    if ((int)s->h_cstart.size() != (s->ncomp ? s->ncomp + 1 : 0) && !(s->ncomp == 0 && s->h_cstart.size() <= 1)) return s->fused_plan;
+    std::vector<int> owned(s->n, 0);
+    for (int a : s->h_settle) owned[a]++;
+    std::vector<int> cas(1, 0), ca, cl(2 * (size_t)s->ncons, 0);
+    for (int c = 0; c < s->ncomp; c++) {
+        const size_t first = ca.size();
+        for (int k = s->h_cstart[c]; k < s->h_cstart[c + 1]; k++) {
+            const int pair[2] = { s->h_cij[k].x, s->h_cij[k].y };
+            for (int e = 0; e < 2; e++) {
+                auto it = std::find(ca.begin() + first, ca.end(), pair[e]);
+                if (it == ca.end()) { ca.push_back(pair[e]); owned[pair[e]]++; it = ca.end() - 1; }
+                cl[2 * (size_t)k + e] = (int)(it - (ca.begin() + first));
+            }
+        }
+        if ((int)(ca.size() - first) > s->h_cstart[c + 1] - s->h_cstart[c] + 1) return s->fused_plan;     // (cannot happen for a connected component)
+        cas.push_back((int)ca.size());
+    }
+    std::vector<int> fr;
+    for (int i = 0; i < s->n; i++) {
+        if (owned[i] > 1) return s->fused_plan;       // an atom in a water and a component: the separate kernels handle that
+        if (owned[i] == 0) fr.push_back(i);
+    }
+    auto up = [&](int **p, const std::vector<int> &h) {
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+        if (hipMalloc((void **)p, sizeof(int) * std::max<size_t>(h.size(), 1)) != hipSuccess) return false;
+        return h.empty() || hipMemcpy(*p, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice) == hipSuccess;
+    };
+    if (!up(&s->comp_atom_start, cas) || !up(&s->comp_atoms, ca) || !up(&s->free_atoms, fr) || !up(&s->comp_local, cl)) return s->fused_plan;
+    s->nfree = (int)fr.size();
+    s->fused_plan = 1;
+    return s->fused_plan;
+}
+
+// The fused update of a step without virial (mdx_fused_plan must have returned 1). write_sorted: also leave the sorted
+// coordinates, the cleared sorted force buffer and the reset unit queues for the next step; fork_signal: the kernel's
+// completion releases the PME and bonded streams (their next kernels read the new positions only).
+int mdx_launch_update_fused(mdx_system *s, bool do_tc, bool do_pr, bool write_sorted, bool fork_signal)
+{
+    FusedArgs A;
+    constrain_args(s, A.C, 1.0f / s->dt, s->lincs_iter);
+    A.L = leap_args(s, do_tc, do_pr, write_sorted);
+    A.nfree = s->nfree; A.nbfree = (s->nfree + 127) / 128; A.free_atoms = s->free_atoms;
+    A.comp_atom_start = s->comp_atom_start; A.comp_atoms = s->comp_atoms; A.comp_local = (const int2 *)s->comp_local;
+    A.write_sorted = write_sorted ? 1 : 0; A.shift_s = s->shift_s; A.xq_s = s->xq_s;
+    const int nb16 = (s->ncomp - s->ncomp_small + MDX_FUSED_LARGE_THREADS - 1) / MDX_FUSED_LARGE_THREADS;
+    A.nbw3 = (s->nsettle + 41) / 42;
+    const int nblocks = A.nbw3 + A.C.nb4 + A.nbfree + nb16;
+    if (nblocks > 0) {
+        if (fork_signal) {
+            hipExtLaunchKernelGGL(k_update_fused, dim3(nblocks), dim3(128), 0, s->stream, nullptr, s->ev_fork, 0, A);
+            MDX_CHECK(s, hipGetLastError());
+            MDX_CHECK(s, hipStreamWaitEvent(s->st_pme, s->ev_fork, 0));
+            MDX_CHECK(s, hipStreamWaitEvent(s->st_bond, s->ev_fork, 0));
+        } else {
+            hipLaunchKernelGGL(k_update_fused, dim3(nblocks), dim3(128), 0, s->stream, A);
+            MDX_CHECK(s, hipGetLastError());
+        }
+    }
     float4 *t = s->x; s->x = s->xp; s->xp = t;
     return MDX_OK;
 }
@@ -534,11 +828,8 @@ int mdx_launch_constrain(mdx_system *s, float inv_dt, bool virial, int lincs_ite
 {
     if (s->nsettle > 0 && s->ncomp > 0) {
         ConstrainArgs A;
-        A.nbw = (s->nsettle + 127) / 128; A.nb4 = (s->ncomp_small + 127) / 128;
+        constrain_args(s, A, inv_dt, lincs_iter);
         const int nb16 = (s->ncomp - s->ncomp_small + 127) / 128;
-        A.nw = s->nsettle; A.settle_idx = s->settle_idx; A.doh = s->settle_doh; A.dhh = s->settle_dhh;
-        A.ncomp_small = s->ncomp_small; A.ncomp = s->ncomp; A.comp_start = s->comp_start; A.cij = s->cons_ij; A.clen = s->cons_len;
-        A.order = s->lincs_order; A.niter = lincs_iter; A.x = s->x; A.xp = s->xp; A.v = s->v; A.inv_dt = inv_dt; A.dw = s->d;
         if (virial) hipLaunchKernelGGL(k_constrain<true>, dim3(A.nbw + A.nb4 + nb16), dim3(128), 0, s->stream, A);
         else hipLaunchKernelGGL(k_constrain<false>, dim3(A.nbw + A.nb4 + nb16), dim3(128), 0, s->stream, A);
         MDX_CHECK(s, hipGetLastError());

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import queue
 import threading
+import time
 
 
 class FramePipeline:
@@ -22,6 +23,9 @@ class FramePipeline:
         for s in range(nslots):
             self.free.put(s)
         self.error = None
+        # where the encoder threads' time goes (seconds, summed over frames): waiting for the copy to land, compressing,
+        # waiting for the turn to commit plus the write itself
+        self.stats = {"frames": 0, "wait_s": 0.0, "encode_s": 0.0, "commit_s": 0.0}
         self._seq = 0
         self._next_commit = 0
         self._cv = threading.Condition()
@@ -45,11 +49,14 @@ class FramePipeline:
             seq, slot, wx, tx, tv = item
             xb = None
             args = None
+            t_a = t_b = t_c = time.perf_counter()
             try:
                 step, x, v, box = self.eng.frame_wait(slot)
+                t_b = time.perf_counter()
                 t = self.tinit + step * self.dt
                 if wx and self.xtc is not None:
                     xb = self.xtc.encode(step, t, box, x if self.sel is None else x[self.sel])
+                t_c = time.perf_counter()
                 if (tx or tv) and self.trr is not None:
                     args = (step, t, box.copy(), x.copy() if tx else None, v.copy() if (tv and v is not None) else None)
             except Exception as e:      # keep draining so that the step loop never blocks on a slot
@@ -67,6 +74,8 @@ class FramePipeline:
                 except Exception as e:
                     self.error = self.error or e
                 self._next_commit += 1
+                st = self.stats
+                st["frames"] += 1; st["wait_s"] += t_b - t_a; st["encode_s"] += t_c - t_b; st["commit_s"] += time.perf_counter() - t_c
                 self._cv.notify_all()
 
     def wait_idle(self):
@@ -74,6 +83,10 @@ class FramePipeline:
         with self._cv:
             while self._next_commit != self._seq:
                 self._cv.wait()
+
+    def pending(self):
+        """Frames submitted and not yet committed."""
+        return self._seq - self._next_commit
 
     def finish(self):
         for _ in self.threads:
