@@ -5,7 +5,8 @@ Workload (N=1 and every N as independent replicas, weak scaling): the synthetic 
 (alkane-bundle "protein" + 44-atom ligand + Na+ + TIP3P, rhombic dodecahedron d = 12.5 nm,
 ~1.4e5 atoms) run with the settings of /root/reference/mdp/production.mdp (dt 2 fs, rc 1.0 nm,
 PME order 4 / 0.16 nm, h-bond constraints, V-rescale on Protein / Non-Protein, energies every
-10 steps, DispCorr EnerPres) and the C-rescale barostat that BASELINE.json's config names.
+10 steps, DispCorr EnerPres, Parrinello-Rahman barostat; --pcoupl c-rescale selects the barostat that BASELINE.json's
+config names instead).
 A "step" is one MD step. Metric: ns/day = dt * steps * 86400 / wall / 1000 summed over replicas.
 """
 import argparse
@@ -180,9 +181,11 @@ def main():
     ap.add_argument("--encoder-threads", type=int, default=0,
                     help="threads that share the compression of one frame (segments); 0: 12 for one rank (they keep the drain of the "
                          "last frame, which a short timed window sees in full, at 0.2 ms), 4 per rank when several ranks share the host")
-    ap.add_argument("--prime-steps", type=int, default=40,
-                    help="un-timed steps before the warmup that run every kernel variant, one pair search, the coupling steps and the "
-                         "frame pipeline once (first launches and first frames carry one-off costs of milliseconds)")
+    ap.add_argument("--prime-steps", type=int, default=400,
+                    help="un-timed steps before the warmup that run every kernel variant, pair searches, the coupling steps and the "
+                         "frame pipeline (first launches and first frames carry one-off costs of milliseconds), and that bring the GPU "
+                         "back to its sustained clocks after the host-side set-up of the run: with 40 of them a 20-step window "
+                         "still saw the nonbonded kernel at 0.123 ms per launch, with 400 at the 0.113 ms of a long run")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -263,10 +266,13 @@ def main():
         if pipe is not None:
             pipe.wait_idle()
             xtc.f.seek(0); xtc.f.truncate(); xtc.frames = 0
-    # ---- warmup
+    # ---- warmup (the event pool of the kernel timer is created ahead of it: two thousand hipEventCreate calls take
+    # the host tens of milliseconds, in which an idle GPU lowers its clocks; the second call only resets the sums)
+    stride = 1 if args.steps <= 500 else 7
+    e.enable_kernel_timing(True, stride=stride)
     e.step(args.warmup); e.synchronize()
     e.pop_energy_frames()
-    e.enable_kernel_timing(True, stride=1 if args.steps <= 500 else 7)
+    e.enable_kernel_timing(True, stride=stride)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -356,6 +362,7 @@ def main():
                         "xtc every 500 steps" % s.natoms),
                        "output": {"xtc_every": nst_xtc, "xtc_frames": xtc_frames, "xtc_MB": round(xtc_bytes / 1e6, 2),
                                   "frames_in_flight": args.encoders if nst_xtc else 0, "threads_per_frame": args.encoder_threads if nst_xtc else 0},
+                       "untimed_steps_before_warmup": args.prime_steps,
                        "natoms": s.natoms, "dt_ps": dt, "rc_nm": e.rc, "rlist_nm": round(e.rlist, 4), "nstlist": args.nstlist,
                        "pme_grid": list(e.grid), "parallelism": "replicas x%d" % world},
             "pair_interactions_per_s": round(n_rc / nb_avg_s, 1) if nb_avg_s > 0 else None,

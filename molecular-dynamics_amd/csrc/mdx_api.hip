@@ -1008,7 +1008,8 @@ extern "C" long long mdx_pop_pull_records(mdx_system *s, double *out, long long 
 
 // Diagnostic: average time of `iters` back-to-back runs of one stage of the step on its own
 // stream, measured with HIP events. stage 1 pair search, 2 PME chain, 3 bonded + exclusion
-// kernels, 4 update + constraints, 5 prepare, 6 PME spread only, 7 PME gather only (dbg bits select ablations).
+// kernels, 4 update + constraints, 5 prepare, 6 PME spread only, 7 PME gather only (dbg bits select ablations),
+// 8 fused update with the next step's sorted coordinates, 9 fused update without them.
 extern "C" int mdx_debug_time_stage(mdx_system *s, int stage, int iters, double *avg_ms)
 {
     (void)hipSetDevice(s->device);
@@ -1030,6 +1031,10 @@ extern "C" int mdx_debug_time_stage(mdx_system *s, int stage, int iters, double 
         case 3: return mdx_launch_bonded(s, false, MDX_F_BONDED | MDX_F_POSRES);
         case 4: { int r = mdx_launch_update(s, false, false, false); float4 *t = s->x; s->x = s->xp; s->xp = t; return r; }
         case 5: return mdx_launch_prepare(s);
+        case 8: case 9: {
+            if (mdx_fused_plan(s) != 1) { s->err = "mdx_debug_time_stage: no fused update for this topology"; return MDX_ERR_ARG; }
+            int r = mdx_launch_update_fused(s, false, false, stage == 8, false); float4 *t = s->x; s->x = s->xp; s->xp = t; return r;
+        }
         default: s->err = "mdx_debug_time_stage: unknown stage"; return MDX_ERR_ARG;
         }
     };
