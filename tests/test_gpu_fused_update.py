@@ -71,3 +71,69 @@ def test_fused_update_water_keeps_geometry_over_a_search(small_water):
     d = np.linalg.norm(x[1::3] - x[2::3], axis=1)
     assert np.abs(d / 0.15139 - 1).max() < 3e-5
     assert np.isfinite(v).all()
+
+
+def _with_chain_constraints(s, nchain=5):
+    """A copy of the system in which `nchain` consecutive heavy-atom bonds of the protein are constrained as well (at
+    their present lengths), so that the h-bond components along them merge into one component of more than four
+    constraints (at most 16: the limit of the LINCS kernels)."""
+    import copy
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    c = np.asarray(s.constraints)
+    in_c = np.zeros(s.natoms, bool); in_c[c.ravel()] = True
+    have = {tuple(sorted(p)) for p in c.tolist()}
+    water = np.zeros(s.natoms, bool); water[np.asarray(s.settles).ravel()] = True
+    # walk along the bonded chain from the first heavy atom that carries constrained hydrogens
+    nb = {}
+    for a, b in np.asarray(s.bonds).tolist():
+        if tuple(sorted((a, b))) in have or water[a] or water[b]:
+            continue
+        nb.setdefault(a, []).append(b); nb.setdefault(b, []).append(a)
+    start = next(a for a in sorted(nb) if in_c[a])
+    chain, seen, cur = [], {start}, start
+    while len(chain) < nchain:
+        nxt = next((b for b in nb.get(cur, []) if b not in seen), None)
+        if nxt is None:
+            break
+        chain.append((cur, nxt)); seen.add(nxt); cur = nxt
+    assert len(chain) == nchain
+    x = np.asarray(s.x, dtype=np.float64)
+    extra = np.array(chain, dtype=c.dtype)
+    t = copy.copy(s)
+    t.constraints = np.concatenate([c, extra])
+    t.constraint_len = np.concatenate([np.asarray(s.constraint_len), np.linalg.norm(x[extra[:, 0]] - x[extra[:, 1]], axis=1)]).astype(
+        np.asarray(s.constraint_len).dtype)
+    cc = t.constraints
+    g = coo_matrix((np.ones(len(cc)), (cc[:, 0], cc[:, 1])), shape=(s.natoms, s.natoms))
+    _, lab = connected_components(g, directed=False)
+    sizes = np.bincount(lab[cc[:, 0]])
+    return t, int(sizes.max())
+
+
+def test_large_constraint_component(small_complex):
+    """A component of 5 to 16 coupled constraints: one step against the oracle's LINCS of the same order, and the fused
+    update (component on 17-atom LDS columns) against the separate LINCS kernel over several steps."""
+    s, kmax = _with_chain_constraints(small_complex, nchain=3)          # 12 coupled constraints
+    assert 4 < kmax <= 16
+    v0 = s.v.astype(np.float32).astype(np.float64)
+    res = []
+    for fused in (1, 0):
+        e = eng.Engine(s, rc=1.0, nstcalcenergy=0, nstcomm=0, dt=0.002, lincs_order=4, lincs_iter=1)
+        e.debug_set(12, fused)
+        e.set_state(s.x, v0, s.box)
+        e.step(1)
+        x1, v1, _ = e.get_state()
+        e.step(6)
+        x7, _, _ = e.get_state()
+        res.append((x1.astype(np.float64), v1.astype(np.float64), x7.astype(np.float64)))
+        e.close()
+    xr, vr, _ = R.md_step(_copy_with(s, s.x, v0), v0, 1.0, e.beta, e.grid, 0.002, nthreads=8)
+    for x1, v1, _ in res:
+        assert np.abs(x1 - xr).max() < 4e-6
+        assert np.abs(v1 - vr).max() < 2e-3
+    assert np.abs(res[0][0] - res[1][0]).max() < 1e-6
+    assert np.sqrt(((res[0][2] - res[1][2]) ** 2).sum(1).mean()) < 2e-6
+    c = s.constraints
+    d = np.linalg.norm(res[0][2][c[:, 0]] - res[0][2][c[:, 1]], axis=1)
+    assert np.abs(d / s.constraint_len - 1).max() < 2e-4
