@@ -4,7 +4,7 @@
 # timeline, and the counter passes of the nonbonded kernel. Each GPU step has its own time limit; the script stops at
 # the first failure.
 set -e
-R=$PWD; O=$R/gpurun_out/r02; mkdir -p $O
+R=$PWD; O=$R/gpurun_out/r02; mkdir -p $O; rm -rf $O/prof
 timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > $O/pytest_gpu.log 2>&1 || { tail -20 $O/pytest_gpu.log; exit 1; }
 tail -2 $O/pytest_gpu.log
 timeout -k 10 200 python -c 'import __graft_entry__ as g; g.smoke()' > $O/smoke.log 2>&1 || { tail -20 $O/smoke.log; exit 1; }
