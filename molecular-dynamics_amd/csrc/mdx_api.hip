@@ -891,7 +891,20 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
         if (phase == 1) return MDX_OK;
     }
     if (phase == 2) if ((rc = mdx_launch_pme(s, need_vir && s->dd_mesh_energy, true))) return rc;
-    if (phase == 0 && s->rotate_streams && s->have_pme && !s->gather_on_main && !s->spread_on_main) {
+    if (phase == 0 && s->rotate_streams == 2 && s->have_pme && !s->one_stream && !s->gather_on_main && !s->spread_on_main && !s->bond_on_main) {
+        // The update goes behind the bonded kernels on their stream, which idles from a few microseconds into the step:
+        // its two waits (PME chain, nonbonded kernel) then stand at the head of an idle queue and are taken as their
+        // signals fire, instead of one after the other once the nonbonded kernel has retired from the main queue.
+        // That stream is the main stream of the next step (the nonbonded kernel follows the update in queue order),
+        // and this one takes the next step's bonded kernels.
+        if (!s->pme_signalled) MDX_CHECK(s, hipEventRecord(s->ev_pme, s->st_pme));
+        s->pme_signalled = false;
+        if (!s->nb_done_event) { MDX_CHECK(s, hipEventRecord(s->ev_nbdone, s->stream)); s->nb_done_event = s->ev_nbdone; }
+        MDX_CHECK(s, hipStreamWaitEvent(s->st_bond, s->ev_pme, 0));
+        MDX_CHECK(s, hipStreamWaitEvent(s->st_bond, s->nb_done_event, 0));
+        s->nb_done_event = nullptr;
+        std::swap(s->stream, s->st_bond);
+    } else if (phase == 0 && s->rotate_streams == 1 && s->have_pme && !s->gather_on_main && !s->spread_on_main) {
         // The PME chain ends about when the nonbonded kernel does. A stream that waits for an event of another one
         // resumes several microseconds after it fires; the update is therefore enqueued behind the gather on the
         // PME stream, which waits for the two other streams (mostly finished by then) and becomes the main stream
@@ -914,7 +927,7 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
         const bool fork_now = phase == 0 && more && !vir_next && !search_next && !do_pc && s->early_fork;
         // Steps that accumulate no virial take leap-frog and constraints in one launch, which (when another step of this
         // call follows on the same pair list and the cell stays as it is) also writes that step's sorted coordinates.
-        const bool fused = phase == 0 && !need_vir && !s->dd_on && s->fused_update && !s->rotate_streams && mdx_fused_plan(s) == 1;
+        const bool fused = phase == 0 && !need_vir && !s->dd_on && s->fused_update && s->rotate_streams != 1 && mdx_fused_plan(s) == 1;
         if (fused) {
             prepared = more && !search_next;
             if ((rc = mdx_launch_update_fused(s, tc_apply, s->pcoupl == 2, prepared, fork_now && prepared))) return rc;

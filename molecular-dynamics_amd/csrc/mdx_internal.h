@@ -121,7 +121,8 @@ struct mdx_system {
     int dbg = 0;                       // diagnostic ablation bits (mdx_debug_set key 2)
     int nb_dyn = 1;                    // nonbonded kernel: rounds' worth of cheap units scheduled dynamically (mdx_debug_set key 3)
     int nb_dyn_split = 0;              // ... in 2^nb_dyn_split parts per unit (mdx_debug_set key 4)
-    int rotate_streams = 0;            // the update follows the PME chain on its stream, which becomes the main stream of the next step (mdx_debug_set key 9)
+    int rotate_streams = 0;            // 1: the update follows the PME chain on its stream, which becomes the main stream of the next step; 2: it follows the bonded kernels on theirs (mdx_debug_set key 9)
+    hipEvent_t nb_done_event = nullptr; // completion signal of the last nonbonded launch (rotate_streams == 2), null: none attached
     int gather_on_main = 0;            // PME gather behind the nonbonded kernel on the main stream: measured slower, the nonbonded kernel ends last (mdx_debug_set key 8)
     const float *gather_pending = nullptr;
     int spread_on_main = 0;            // charge spreading on the main stream ahead of the nonbonded kernel: measured slower (mdx_debug_set key 7)
