@@ -285,12 +285,15 @@ class DecomposedWater:
                  ref_t: float | None = 300.0, tau_t: float = 0.1, nsttcouple: int = 10, fourierspacing: float = 0.16,
                  rlist: float | None = None, seed: int = 1, group=None, dims=None, nstcalcenergy: int = 0,
                  transport=None, global_coupling: bool = True, nstcomm: int = 0, pcoupl: str | None = None, tau_p: float = 2.0,
-                 ref_p: float = 1.0, compressibility: float = 4.5e-5, nstpcouple: int = 10):
+                 ref_p: float = 1.0, compressibility: float = 4.5e-5, nstpcouple: int = 10, dispcorr: int = 0):
         """global_coupling: one V-rescale factor for the whole system from the kinetic energy summed over the domains
         (every domain draws it from the same random stream); False: every domain is its own thermostat group.
         nstcomm > 0: centre-of-mass motion of the whole system removed every nstcomm steps.
         pcoupl = "c-rescale": isotropic stochastic cell rescaling from the pressure summed over the domains, every nstpcouple
-        steps (needs the shared thermostat seed: every domain draws the same factor)."""
+        steps (needs the shared thermostat seed: every domain draws the same factor).
+        dispcorr: 1 adds the analytic long-range dispersion correction of the whole system (`DispCorr = Ener`) to the
+        energies, 2 (`EnerPres`, /root/reference/mdp/production.mdp:44) also to the pressure, the coupled one included: it
+        depends on the atom count, the volume and <C6> of the whole system only, so every rank evaluates it itself."""
         from . import engine as eng
         self.tr = transport if transport is not None else Transport(group)
         self.rank, self.world = self.tr.rank, self.tr.world
@@ -325,6 +328,8 @@ class DecomposedWater:
         if self.pcoupl and not global_coupling:
             raise ValueError("pressure coupling across domains needs global_coupling (one random stream for all domains)")
         self.nstpcouple = int(nstpcouple)
+        self.dispcorr, self.rc, self.natoms = int(dispcorr), float(rc), int(n)
+        self.c6avg = eng.c6_average(np.asarray(sysm.sigma), np.asarray(sysm.eps)) if self.dispcorr else 0.0
         self.rlist_margin = self.rlist + 2 * MOL_RADIUS + 0.02
         self.engine = eng.Engine(tmpl, rc=rc, rlist=self.rlist, dt=dt, nstlist=nstlist, pme=True, grid=grid, device=device,
                                  tc_groups=["System"] if ref_t is not None else None, ref_t=[ref_t or 300.0], tau_t=[tau_t],
@@ -480,12 +485,18 @@ class DecomposedWater:
             with self._exclusive():
                 say("end"); self.engine.dd_step_end()
             done = self.nsteps_done + 1
+            if self.nstcalcenergy > 0 and self.nsteps_done % self.nstcalcenergy == 0:
+                self._volume_at_energy = self.volume
             if self.pcoupl and self.nsteps_done % self.nstpcouple == 0:
                 # the step left this domain's share of the pressure in the scalars: sum it, scale every domain alike, and
                 # put the share back (energies() adds the shares up itself)
                 self.engine.dd_stream_sync()
                 share = self.pres_t.clone()
-                self.tr.all_reduce_sum_(self.pres_t); torch.cuda.synchronize(self.dev)
+                self.tr.all_reduce_sum_(self.pres_t)
+                pdisp = self.dispersion_correction()[1]
+                if pdisp != 0.0:
+                    self.pres_t[0::4] += pdisp
+                torch.cuda.synchronize(self.dev)
                 with self._exclusive():
                     box = self.engine.dd_pcouple()
                 self.pres_t.copy_(share); torch.cuda.synchronize(self.dev)
@@ -508,6 +519,17 @@ class DecomposedWater:
             self.steps_since_partition += 1
             self.nsteps_done += 1
 
+    def dispersion_correction(self):
+        """(energy, pressure) of the long-range dispersion correction at the present volume, as the single handle's
+        energy kernel evaluates them: the tail integral plus the constant the potential shift removes inside the cutoff
+        (together twice the tail), and the tail's pressure for mode 2."""
+        if not self.dispcorr:
+            return 0.0, 0.0
+        nn = float(self.natoms) ** 2
+        etail = -(2.0 / 3.0) * np.pi * nn / self.volume * self.c6avg / self.rc ** 3
+        pdisp = -(4.0 / 3.0) * np.pi * nn / self.volume ** 2 * self.c6avg / self.rc ** 3 * U.PRESFAC if self.dispcorr == 2 else 0.0
+        return 2.0 * etail, pdisp
+
     def synchronize(self):
         self.engine.synchronize()
 
@@ -526,9 +548,19 @@ class DecomposedWater:
         self.tr.all_reduce_sum_(t); torch.cuda.synchronize(self.dev)
         vec = t.cpu().numpy()
         out = {k: float(vec[i]) for i, k in enumerate(names)}
-        out["POT"] = out["LJ"] + out["COUL_SR"] + out["COUL_RECIP"] + out["COUL_EXCL"]
+        # (the frame is that of the last energy step; with pressure coupling on the same step the cell has been scaled
+        # since: the correction is taken at the volume the step ran in)
+        vol_now = self.volume
+        self.volume = getattr(self, "_volume_at_energy", self.volume)
+        edisp, pdisp = self.dispersion_correction()
+        self.volume = vol_now
+        out["DISPCORR"] = edisp
+        out["POT"] = out["LJ"] + out["COUL_SR"] + out["COUL_RECIP"] + out["COUL_EXCL"] + edisp
+        out["PRES"] += pdisp
+        pres = vec[16:25].reshape(3, 3).copy()
+        pres[0, 0] += pdisp; pres[1, 1] += pdisp; pres[2, 2] += pdisp
         out["VOLUME"] = self.volume
-        return out, vec[7:16].reshape(3, 3), vec[16:25].reshape(3, 3)
+        return out, vec[7:16].reshape(3, 3), pres
 
     def gather_state(self):
         """Positions and velocities of the whole system, (N, 3) each, in the original molecule order (every rank)."""

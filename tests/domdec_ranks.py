@@ -69,7 +69,7 @@ def coupled_npt(world, nst, d):
     from mdx import synth, domdec, engine as eng
     hub = domdec.ThreadTransport.Hub(world)
     kw = dict(rc=1.0, dt=0.002, nstlist=10, rlist=1.1)
-    pk = dict(tau_p=1.0, ref_p=1.0, compressibility=4.5e-5, nstpcouple=10)
+    pk = dict(tau_p=1.0, ref_p=1.0, compressibility=4.5e-5, nstpcouple=10, dispcorr=2)     # DispCorr = EnerPres as in production.mdp
 
     def rank_main(rank, transport):
         dd = domdec.DecomposedWater(synth.water_box(d=d), device=0, ref_t=300.0, tau_t=0.1, nsttcouple=10, nstcalcenergy=10,
@@ -92,7 +92,8 @@ def coupled_npt(world, nst, d):
     dx -= np.round(dx @ np.linalg.inv(boxr)) @ boxr
     return dict(box_rel_diff=float(np.abs(o["box"] - boxr).max() / np.abs(boxr).max()),
                 box_change=float(abs(boxr[0, 0] / s.box[0][0] - 1.0)), dx_rms=float(np.sqrt((dx ** 2).mean())),
-                pot_dd=o["e"]["POT"], pot_single=er["POT"], pres_max_diff=float(np.abs(o["pres"] - presr).max()))
+                pot_dd=o["e"]["POT"], pot_single=er["POT"], pres_max_diff=float(np.abs(o["pres"] - presr).max()),
+                dispcorr_dd=o["e"]["DISPCORR"], dispcorr_single=er["DISPCORR"])
 
 
 def main(world=2, steps=12, d=7.0):

@@ -50,6 +50,9 @@ def test_domains_match_single_handle(world, box):
     assert p["box_rel_diff"] < 1e-6, p
     assert p["dx_rms"] < 5e-6, p
     assert abs(p["pot_dd"] - p["pot_single"]) < 2e-5 * abs(p["pot_single"]) and p["pres_max_diff"] < 3.0, p
+    # the long-range dispersion correction (DispCorr = EnerPres) is in both: the energy term itself, and through the
+    # pressure the cell above
+    assert p["dispcorr_single"] < -10.0 and abs(p["dispcorr_dd"] - p["dispcorr_single"]) < 1e-6 * abs(p["dispcorr_single"]), p
 
 
 @pytest.mark.gpu
