@@ -178,8 +178,10 @@ extern "C" int mdx_dd_tcouple(mdx_system *s, int before_first_step)
 // Pressure coupling across the domains (C-rescale): on a coupling step every domain's step leaves its share of the
 // pressure tensor in the scalars (the shares add up: half-weighted home-halo pairs, home kinetic energy). The caller sums
 // the 9 doubles at `pres_dev` over the domains and calls mdx_dd_pcouple: every domain draws the same scaling factor
-// (same seed, keyed by the step just completed as inside mdx_step), scales its box, its atoms (copies included) and its
-// velocities, and returns the new box (9 doubles, rows = cell vectors). The call waits for the main stream.
+// (C-rescale: same seed, keyed by the step just completed as inside mdx_step) or advances the same box velocity
+// (Parrinello-Rahman: the box state is replicated on every domain and sees the same summed pressure), scales its box,
+// its atoms (copies included) and, for C-rescale, its velocities, and returns the new box (9 doubles, rows = cell
+// vectors). The call waits for the main stream.
 extern "C" int mdx_dd_pressure(mdx_system *s, void **pres_dev)
 {
     if (pres_dev) *pres_dev = (char *)s->d + offsetof(DevState, pres);
@@ -189,7 +191,7 @@ extern "C" int mdx_dd_pcouple(mdx_system *s, double *box9)
 {
     (void)hipSetDevice(s->device);
     if (!s->dd_on) { s->err = "mdx_dd_pcouple: no partition loaded"; return MDX_ERR_ARG; }
-    if (s->pcoupl != 1) { s->err = "mdx_dd_pcouple: the decomposed path couples the pressure with C-rescale only"; return MDX_ERR_UNSUPPORTED; }
+    if (s->pcoupl != 1 && s->pcoupl != 2) { s->err = "mdx_dd_pcouple: no pressure coupling set up"; return MDX_ERR_UNSUPPORTED; }
     s->step--;
     const int rc = mdx_launch_pcouple(s);
     s->step++;

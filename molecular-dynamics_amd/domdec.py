@@ -290,7 +290,9 @@ class DecomposedWater:
         (every domain draws it from the same random stream); False: every domain is its own thermostat group.
         nstcomm > 0: centre-of-mass motion of the whole system removed every nstcomm steps.
         pcoupl = "c-rescale": isotropic stochastic cell rescaling from the pressure summed over the domains, every nstpcouple
-        steps (needs the shared thermostat seed: every domain draws the same factor).
+        steps (needs the shared thermostat seed: every domain draws the same factor); "parrinello-rahman"
+        (/root/reference/mdp/production.mdp:36): every domain carries the same box velocity and advances it with the summed
+        pressure.
         dispcorr: 1 adds the analytic long-range dispersion correction of the whole system (`DispCorr = Ener`) to the
         energies, 2 (`EnerPres`, /root/reference/mdp/production.mdp:44) also to the pressure, the coupled one included: it
         depends on the atom count, the volume and <C6> of the whole system only, so every rank evaluates it itself."""
@@ -322,9 +324,10 @@ class DecomposedWater:
         self.cap = min(self.home_cap + self.halo_cap, self.nmol + 256)
         tmpl = _template(self.cap, self.box_np)
         grid = U.pme_grid(self.box_np, fourierspacing)
-        if pcoupl not in (None, "no", "c-rescale"):
-            raise ValueError("the decomposed path couples the pressure with c-rescale only")
-        self.pcoupl = pcoupl == "c-rescale"
+        if pcoupl not in (None, "no", "c-rescale", "parrinello-rahman"):
+            raise ValueError("pcoupl: c-rescale or parrinello-rahman")
+        self.pcoupl = pcoupl in ("c-rescale", "parrinello-rahman")
+        pc_kind = {"c-rescale": 1, "parrinello-rahman": 2}.get(pcoupl, 0)
         if self.pcoupl and not global_coupling:
             raise ValueError("pressure coupling across domains needs global_coupling (one random stream for all domains)")
         self.nstpcouple = int(nstpcouple)
@@ -334,7 +337,7 @@ class DecomposedWater:
         self.engine = eng.Engine(tmpl, rc=rc, rlist=self.rlist, dt=dt, nstlist=nstlist, pme=True, grid=grid, device=device,
                                  tc_groups=["System"] if ref_t is not None else None, ref_t=[ref_t or 300.0], tau_t=[tau_t],
                                  nsttcouple=nsttcouple, nstcalcenergy=nstcalcenergy, nstcomm=0,
-                                 pcoupl=1 if self.pcoupl else 0, tau_p=tau_p, ref_p=ref_p, compressibility=compressibility,
+                                 pcoupl=pc_kind, tau_p=tau_p, ref_p=ref_p, compressibility=compressibility,
                                  nstpcouple=nstpcouple, seed=seed if global_coupling else seed + self.rank)
         if self.pcoupl:
             self.pres_t = torch.as_tensor(_DevArray(self.engine.dd_pressure(), (9,), "<f8"), device=self.dev)

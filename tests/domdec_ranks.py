@@ -61,7 +61,7 @@ def coupled(world, nst, d):
                 com_v=[float(c) for c in (s.mass[:, None] * o["v"]).sum(0) / s.mass.sum()])
 
 
-def coupled_npt(world, nst, d):
+def coupled_npt(world, nst, d, kind="c-rescale"):
     """C-rescale pressure coupling across the domains against the single handle: same seed, so the same stochastic
     scaling factors as long as the summed pressure agrees; the cell after `nst` steps (three coupling steps) and the
     positions are compared."""
@@ -73,7 +73,7 @@ def coupled_npt(world, nst, d):
 
     def rank_main(rank, transport):
         dd = domdec.DecomposedWater(synth.water_box(d=d), device=0, ref_t=300.0, tau_t=0.1, nsttcouple=10, nstcalcenergy=10,
-                                    seed=11, transport=transport, pcoupl="c-rescale", **pk, **kw)
+                                    seed=11, transport=transport, pcoupl=kind, **pk, **kw)
         dd.step(nst); dd.synchronize()
         e, vir, pres = dd.energies()
         x, v = dd.gather_state()
@@ -83,7 +83,7 @@ def coupled_npt(world, nst, d):
     o = hub.run(rank_main)[0]
     s = synth.water_box(d=d)
     e = eng.Engine(s, tc_groups=["System"], ref_t=[300.0], tau_t=[0.1], nsttcouple=10, nstcalcenergy=10, nstcomm=0, seed=11,
-                   pcoupl=1, **pk, **kw)
+                   pcoupl=1 if kind == "c-rescale" else 2, **pk, **kw)
     e.step(nst); e.synchronize()
     er = e.energies(); _, presr = e.virial()
     xr, _, boxr = e.get_state(); e.close()
@@ -115,6 +115,7 @@ def main(world=2, steps=12, d=7.0):
                           dv_rel_rms=float(np.sqrt(((o["v"] - vr) ** 2).mean() / (vr ** 2).mean())), partition=o["info"])
     res["coupled"] = coupled(world, 21, d)
     res["npt"] = coupled_npt(world, 21, d)
+    res["npt_pr"] = coupled_npt(world, 21, d, "parrinello-rahman")
     print(json.dumps(res), flush=True)
 
 

@@ -50,6 +50,10 @@ def test_domains_match_single_handle(world, box):
     assert p["box_rel_diff"] < 1e-6, p
     assert p["dx_rms"] < 5e-6, p
     assert abs(p["pot_dd"] - p["pot_single"]) < 2e-5 * abs(p["pot_single"]) and p["pres_max_diff"] < 3.0, p
+    # Parrinello-Rahman across the domains (the barostat of production.mdp): the same box velocity on every domain
+    q = res["npt_pr"]
+    assert q["box_change"] > 1e-7 and q["box_rel_diff"] < 1e-6 and q["dx_rms"] < 5e-6, q
+    assert abs(q["pot_dd"] - q["pot_single"]) < 2e-5 * abs(q["pot_single"]) and q["pres_max_diff"] < 3.0, q
     # the long-range dispersion correction (DispCorr = EnerPres) is in both: the energy term itself, and through the
     # pressure the cell above
     assert p["dispcorr_single"] < -10.0 and abs(p["dispcorr_dd"] - p["dispcorr_single"]) < 1e-6 * abs(p["dispcorr_single"]), p
