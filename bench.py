@@ -17,6 +17,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+JSON_OUT = sys.stdout
 
 import numpy as np  # noqa: E402
 
@@ -132,7 +133,7 @@ def run_dd(args, rank, world, local):
                                    % (big.natoms, "x".join(str(d) for d in dd.dims)),
                        "natoms": big.natoms, "home_molecules_rank0": dd.n_home, "halo_molecules_rank0": dd.n_halo,
                        "rlist_nm": round(dd.rlist, 4), "nstlist": args.nstlist, "pme_grid": list(dd.engine.grid),
-                       "parallelism": "dd%d" % world}}), flush=True)
+                       "parallelism": "dd%d" % world}}), file=JSON_OUT, flush=True)
     dd.close()
     if world > 1:
         dist.destroy_process_group()
@@ -157,6 +158,16 @@ def launch_ranks(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.run(cmd, env=env).returncode
+
+
+def private_stdout():
+    """The JSON line must be the only thing on stdout, but RCCL prints a version banner there when its communicator is
+    created. File descriptor 1 is therefore pointed at stderr for the life of the process (C libraries included) and the
+    original stdout is kept for the one line."""
+    sys.stdout.flush()
+    keep = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return keep
 
 
 def main():
@@ -190,6 +201,8 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)
+    global JSON_OUT
+    JSON_OUT = private_stdout()
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -203,8 +216,14 @@ def main():
         args.encoder_threads = 12 if world == 1 else 4
     use_dist = world > 1 or bool(os.environ.get("MDX_BENCH_FORCE_DIST"))     # the latter: rehearsal of the N>1 code path on one GPU
     ctl = None
-    if use_dist and args.workload == "dd":
+    if use_dist and (args.workload == "dd" or os.environ.get("MDX_BENCH_EAGER_RCCL")):      # (the latter: diagnostic)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))       # collectives in every step
+        # The communicator's first collective is completed before any engine handle exists: handles created between an
+        # eager initialisation and that first collective run their three-stream step a third slower for the rest of the
+        # process (259 against 175 us per step on the production workload, tools/rccl_queue_probe.py); handles created
+        # before the initialisation or after the first collective do not.
+        if not os.environ.get("MDX_BENCH_NO_FIRST_COLLECTIVE"):
+            first = torch.ones(1, device="cuda"); dist.all_reduce(first); torch.cuda.synchronize()
     elif use_dist:
         # Replicas exchange nothing while they run: their one collective (the work curves / final energies, RCCL) comes
         # after the timed region. The RCCL communicator is therefore left to be created by that first collective, and the
@@ -319,7 +338,7 @@ def main():
         os.remove(xtc_path)
     nb_ms, nb_launches = e.kernel_timing()
     e.enable_kernel_timing(False)
-    tmax = torch.tensor([elapsed], dtype=torch.float64)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if (ctl is not None or not use_dist) else "cuda")
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=ctl)
     elapsed_max = float(tmax.item())
@@ -436,7 +455,7 @@ def main():
             out["roofline_secondary"] = sec
         except Exception as ex:      # diagnostics must not lose the bench line
             out["roofline_secondary"] = "failed: %s" % ex
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=JSON_OUT, flush=True)
     e.close()
     if use_dist:
         dist.destroy_process_group()
