@@ -217,7 +217,10 @@ def main():
     use_dist = world > 1 or bool(os.environ.get("MDX_BENCH_FORCE_DIST"))     # the latter: rehearsal of the N>1 code path on one GPU
     ctl = None
     if use_dist and (args.workload == "dd" or os.environ.get("MDX_BENCH_EAGER_RCCL")):      # (the latter: diagnostic)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))       # collectives in every step
+        if os.environ.get("MDX_BENCH_DD_LAZY"):      # diagnostic
+            dist.init_process_group("nccl")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))       # collectives in every step
         # The communicator's first collective is completed before any engine handle exists: handles created between an
         # eager initialisation and that first collective run their three-stream step a third slower for the rest of the
         # process (259 against 175 us per step on the production workload, tools/rccl_queue_probe.py); handles created
