@@ -16,6 +16,8 @@
 #include <type_traits>
 #include <cstddef>
 
+typedef float v2f __attribute__((ext_vector_type(2)));      // two floats in an even-aligned register pair: operands of the packed FP32 instructions
+
 struct NbArgs {
     const DevState *d;
     const NbWork *work;
@@ -170,20 +172,24 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
         for (int half = 0; half < 8 / NI; half++) {
         const int c0 = half * NI;
         constexpr bool ILDS = (ABL & 16) != 0;
-        float xi[NI], yi[NI], zi[NI], qi[NI], hsi[ILDS ? 1 : NI], sei[ILDS ? 1 : NI];
+        constexpr bool PK = (ABL & 128) != 0;       // x and y of positions and forces as register pairs (packed subtract and fma)
+        float xi[PK ? 1 : NI], yi[PK ? 1 : NI], zi[NI], qi[NI], hsi[ILDS ? 1 : NI], sei[ILDS ? 1 : NI];
+        v2f xyi[PK ? NI : 1], fixy[PK ? NI : 1];
         float2 *myilj = ILDS ? ilj + (threadIdx.x >> 6) * 64 : nullptr;
         if (ILDS) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // the previous pass has read its values
-        float fix[NI], fiy[NI], fiz[NI];
+        float fix[PK ? 1 : NI], fiy[PK ? 1 : NI], fiz[NI];
         // (one load and one LDS store per wave: lane l brings the pair of the l-th i-atom)
         if (ILDS && lane < NI * 8) myilj[lane] = *at32(A.lj_s, (unsigned)((sci * 8 + c0) * 8 + lane));
 #pragma unroll
         for (int c = 0; c < NI; c++) {
             const int ia = (sci * 8 + c0 + c) * 8 + ti;
             const float4 p = *at32(A.xq_s, (unsigned)ia);
-            xi[c] = p.x - S.x; yi[c] = p.y - S.y; zi[c] = p.z - S.z;
+            if (PK) { xyi[c] = (v2f){ p.x - S.x, p.y - S.y }; fixy[c] = (v2f){ 0.0f, 0.0f }; }
+            else { xi[c] = p.x - S.x; yi[c] = p.y - S.y; fix[c] = 0.0f; fiy[c] = 0.0f; }
+            zi[c] = p.z - S.z;
             qi[c] = p.w * MDX_ONE_4PI_EPS0;
             if (!ILDS) { const float2 l = A.lj_s[ia]; hsi[c] = l.x; sei[c] = l.y; }
-            fix[c] = 0.0f; fiy[c] = 0.0f; fiz[c] = 0.0f;
+            fiz[c] = 0.0f;
         }
         // (LDS operations of one wave execute in order; the fence only keeps the compiler from moving the reads of
         // other lanes' values above the writes)
@@ -221,6 +227,8 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                 exh = ex >> c0;
             }
             float fjx = 0.0f, fjy = 0.0f, fjz = 0.0f;
+            v2f fjxy = (v2f){ 0.0f, 0.0f };
+            const v2f pjxy = (v2f){ pj.x, pj.y };
             bool did = false;           // wave-uniform: some tile of this entry had a pair inside the cutoff
             // One 8x8 tile: i-cluster c against the j-cluster. GENERAL tiles look at the exclusion and
             // liveness bits; the others (no mask slot, not a cluster with itself: the large majority, and
@@ -228,7 +236,9 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
             // shorter. The 1e-12 inside r2 keeps a filler atom, which sits exactly on a real one, finite.
             auto tile = [&](auto general_tag, const int c) {
                 constexpr bool GENERAL = decltype(general_tag)::value;
-                const float dx = xi[c] - pj.x, dy = yi[c] - pj.y, dz = zi[c] - pj.z;
+                v2f dxy;
+                if (PK) dxy = xyi[c] - pjxy; else dxy = (v2f){ xi[c] - pj.x, yi[c] - pj.y };
+                const float dx = dxy.x, dy = dxy.y, dz = zi[c] - pj.z;
                 const float r2 = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, 1.0e-12f)));
                 bool within = r2 < rc2;
                 if (GENERAL) within = within && ((live >> c) & 1u);
@@ -296,8 +306,17 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                 }
                 fs = within ? fs : 0.0f;
                 const float fx = fs * dx, fy = fs * dy, fz = fs * dz;
-                fix[c] += fx; fiy[c] += fy; fiz[c] += fz;
-                fjx -= fx; fjy -= fy; fjz -= fz;
+                if (PK) {
+                    // two packed fmas for x and y of both atoms' forces (four plain ones otherwise)
+                    const v2f fs2 = (v2f){ fs, fs };
+                    fixy[c] = __builtin_elementwise_fma(dxy, fs2, fixy[c]);
+                    fjxy = __builtin_elementwise_fma(-dxy, fs2, fjxy);
+                    fiz[c] = fmaf(dz, fs, fiz[c]);
+                    fjz = fmaf(-dz, fs, fjz);
+                } else {
+                    fix[c] += fx; fiy[c] += fy; fiz[c] += fz;
+                    fjx -= fx; fjy -= fy; fjz -= fz;
+                }
                 if (ENERGY) {
                     // A pair between an atom of this domain and a copy of another domain's atom is evaluated by both
                     // owners: each takes half of its energy and virial; a pair of two copies belongs to others entirely.
@@ -346,6 +365,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
             asm volatile("" :: "v"(N.pj.x), "v"(N.pj.y), "v"(N.pj.z), "v"(N.pj.w), "v"(N.lj.x), "v"(N.lj.y), "v"(N.ex));
             // an entry none of whose tiles had a pair inside the cutoff has no j-force to reduce or add
             float fj3 = 0.0f;
+            if (PK) { fjx = fjxy.x; fjy = fjxy.y; }
             if (did && !(ABL & 2)) fj3 = sum8_xyz(fjx, fjy, fjz, (ti & 1) != 0, (ti & 2) != 0);
             // (one 24-lane atomic per entry: pairing two entries into one 48-lane atomic costs more VALU instructions in
             // the selects than the second atomic costs now that no wait sits behind it)
@@ -363,7 +383,8 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
         }
 #pragma unroll
         for (int c = 0; c < NI; c++) {
-            float ax = fix[c], ay = fiy[c], az = fiz[c];
+            float ax, ay, az = fiz[c];
+            if (PK) { ax = fixy[c].x; ay = fixy[c].y; } else { ax = fix[c]; ay = fiy[c]; }
             // (x, y, z over the eight j-lanes of an i-atom with the same keep-one-give-one exchanges as sum8_xyz: the lanes
             // with tj = 0, 1, 2 end with the sums of x, y, z)
             const bool t0 = (tj & 1) != 0, t1 = (tj & 2) != 0;
@@ -438,6 +459,16 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int k = threadIdx.x; k < MDX_GTAB_N / 2; k += 768) tab4[k] = src[k];
     __syncthreads();
     nb_body<false, false, 4 | 16>(A, (const float2 *)tab4, ilj);
+}
+// The same with x and y of the positions and forces in register pairs (packed FP32 subtract and fma).
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_f3tlp(NbArgs A)
+{
+    __shared__ float4 tab4[MDX_GTAB_N / 2];
+    __shared__ float2 ilj[12 * 64];
+    const float4 *src = (const float4 *)A.gtab;
+    for (int k = threadIdx.x; k < MDX_GTAB_N / 2; k += 768) tab4[k] = src[k];
+    __syncthreads();
+    nb_body<false, false, 4 | 16 | 128>(A, (const float2 *)tab4, ilj);
 }
 // The same with the run-time switches that leave out the force atomics (timing experiments: mdx_debug_set key 2, bits
 // 0x20000 and 0x40000); the production kernel does not carry their tests.
@@ -581,7 +612,7 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
         else if (s->dbg & 0x100000) kern = k_nonbonded_f3_abl1;
         else if (s->dbg & 0x200000) kern = k_nonbonded_f3_abl2;
         else if ((s->dbg & 0x400000) || !s->gtab) kern = k_nonbonded_f3;
-        else { kern = (s->dbg & 0x800000) ? k_nonbonded_f3t128 : ((s->dbg & 0x4000000) ? k_nonbonded_f3t : ((s->dbg & 0x60000) ? k_nonbonded_f3tl_abl : k_nonbonded_f3tl)); grid = dim3(256); block = dim3(768); }
+        else { kern = (s->dbg & 0x800000) ? k_nonbonded_f3t128 : ((s->dbg & 0x4000000) ? k_nonbonded_f3t : ((s->dbg & 0x60000) ? k_nonbonded_f3tl_abl : ((s->dbg & 0x8000000) ? k_nonbonded_f3tlp : k_nonbonded_f3tl))); grid = dim3(256); block = dim3(768); }
     } else if (wv == 4 && s->gtab && !(s->dbg & 0x400000)) { kern = k_nonbonded_f4tl4; grid = dim3(256); block = dim3(1024); }
     // (rotate_streams == 2: the update waits for this launch on another stream; the kernel's own completion signal
     // serves, a marker recorded behind it would fire microseconds later)
