@@ -28,17 +28,18 @@ __device__ __forceinline__ void add_force(const ForceWin &f, int i, float3 v) { 
 // Block-reduce an energy and a 3x3 virial contribution (sum d (x) F, not yet scaled by -1/2).
 __device__ void accum_ev(double e, const float *v9, DevState *dw, int eidx, double e2 = 0.0, int eidx2 = -1)
 {
-    __shared__ double red[16];
-    double r = block_sum_d(e, red);
-    if (threadIdx.x == 0 && r != 0.0) atomicAdd(&MDX_ENER(dw, eidx), r);
-    if (eidx2 >= 0) {
-        r = block_sum_d(e2, red);
-        if (threadIdx.x == 0 && r != 0.0) atomicAdd(&MDX_ENER(dw, eidx2), r);
-    }
-    for (int k = 0; k < 9; k++) {
-        r = block_sum_d((double)v9[k], red);
-        if (threadIdx.x == 0 && r != 0.0) atomicAdd(&MDX_VIR(dw, k), -0.5 * r);
-    }
+    // two energies and the nine virial sums in one reduction; thread k adds the k-th
+    __shared__ double red[16 * 11];
+    double all[11];
+    all[0] = e; all[1] = e2;
+#pragma unroll
+    for (int k = 0; k < 9; k++) all[2 + k] = (double)v9[k];
+    const double r = block_sum_n<11>(all, red);
+    const int t = threadIdx.x;
+    if (r == 0.0) return;
+    if (t == 0) atomicAdd(&MDX_ENER(dw, eidx), r);
+    else if (t == 1) { if (eidx2 >= 0) atomicAdd(&MDX_ENER(dw, eidx2), r); }
+    else if (t < 11) atomicAdd(&MDX_VIR(dw, t - 2), -0.5 * r);
 }
 
 __device__ __forceinline__ void outer_acc(float *v9, float3 d, float3 f)

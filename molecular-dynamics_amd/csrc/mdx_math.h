@@ -61,6 +61,27 @@ __device__ __forceinline__ double block_sum_d(double v, double *smem /* >= 16 do
     return r;
 }
 
+// Block-wide sums of N values at once (blockDim.x <= 1024, a multiple of 64, and >= N): thread k < N returns the sum of
+// v[k], the other threads 0. One pair of barriers for all N values; N calls of block_sum_d cost N pairs, and the kernels
+// of the energy steps sum seven to fourteen values per workgroup.
+template <int N>
+__device__ __forceinline__ double block_sum_n(const double (&v)[N], double *smem /* >= 16 * N doubles */)
+{
+    double w[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) w[k] = wave_sum_d(v[k]);
+    const int wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < N; k++) smem[wv * N + k] = w[k];
+    }
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x < N) for (int i = 0; i < nw; i++) r += smem[i * N + threadIdx.x];
+    return r;
+}
+
 // Triclinic box in device memory: rows a=(h0,0,0) b=(h3,h4,0) c=(h6,h7,h8); inv = h^-1 with
 // fractional s = x . inv (s_d = sum_e x_e inv[3e+d]).
 struct DevBox {

@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void k_pme_solve(float2 *__restrict__ cgrid, c
                                                    int K0, int K1, int K2, const float *__restrict__ bm0,
                                                    const float *__restrict__ bm1, const float *__restrict__ bm2, float beta)
 {
-    __shared__ double red[16];
+    __shared__ double red[16 * 7];
     const int K0c = K0 / 2 + 1;
     const size_t total = (size_t)K2 * K1 * K0c;
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -479,15 +479,14 @@ __global__ __launch_bounds__(256) void k_pme_solve(float2 *__restrict__ cgrid, c
         }
     }
     if (ENERGY) {
-        double r = block_sum_d(e, red);
-        if (threadIdx.x == 0) atomicAdd(&MDX_ENER(dw, MDX_E_COUL_RECIP), r);
+        const double ev[7] = { e, v[0], v[1], v[2], v[3], v[4], v[5] };
+        const double r = block_sum_n<7>(ev, red);
         const int map[6][2] = { { 0, 0 }, { 1, 3 }, { 2, 6 }, { 4, 4 }, { 5, 7 }, { 8, 8 } };
-        for (int k = 0; k < 6; k++) {
-            r = block_sum_d(v[k], red);
-            if (threadIdx.x == 0) {
-                atomicAdd(&MDX_VIR(dw, map[k][0]), -0.5 * r);
-                if (map[k][1] != map[k][0]) atomicAdd(&MDX_VIR(dw, map[k][1]), -0.5 * r);
-            }
+        if (threadIdx.x == 0) atomicAdd(&MDX_ENER(dw, MDX_E_COUL_RECIP), r);
+        else if (threadIdx.x < 7) {
+            const int k = threadIdx.x - 1;
+            atomicAdd(&MDX_VIR(dw, map[k][0]), -0.5 * r);
+            if (map[k][1] != map[k][0]) atomicAdd(&MDX_VIR(dw, map[k][1]), -0.5 * r);
         }
     }
 }
@@ -841,16 +840,16 @@ __global__ __launch_bounds__(256) void k_pme_fft(FftArgs A)
             a[c * stride + k2] = cv;
         }
         if (ENERGY) {
-            __shared__ double red[16];
-            double r = block_sum_d(e, red);
-            if (threadIdx.x == 0) atomicAdd(&MDX_ENER(A.dw, MDX_E_COUL_RECIP), r);
+            // energy and the six virial sums in one reduction; thread k adds the k-th of them
+            __shared__ double red[16 * 7];
+            const double ev[7] = { e, v[0], v[1], v[2], v[3], v[4], v[5] };
+            const double r = block_sum_n<7>(ev, red);
             const int map[6][2] = { { 0, 0 }, { 1, 3 }, { 2, 6 }, { 4, 4 }, { 5, 7 }, { 8, 8 } };
-            for (int k = 0; k < 6; k++) {
-                r = block_sum_d(v[k], red);
-                if (threadIdx.x == 0) {
-                    atomicAdd(&MDX_VIR(A.dw, map[k][0]), -0.5 * r);
-                    if (map[k][1] != map[k][0]) atomicAdd(&MDX_VIR(A.dw, map[k][1]), -0.5 * r);
-                }
+            if (threadIdx.x == 0) atomicAdd(&MDX_ENER(A.dw, MDX_E_COUL_RECIP), r);
+            else if (threadIdx.x < 7) {
+                const int k = threadIdx.x - 1;
+                atomicAdd(&MDX_VIR(A.dw, map[k][0]), -0.5 * r);
+                if (map[k][1] != map[k][0]) atomicAdd(&MDX_VIR(A.dw, map[k][1]), -0.5 * r);
             }
         }
         __syncthreads();

@@ -145,11 +145,13 @@ __device__ __forceinline__ void d_settle(const int t, int nw, const int4 *__rest
         v[a.x] = vo; v[a.y] = vh1; v[a.z] = vh2;
     }
     if (VIRIAL) {
-        __shared__ double red[16];
-        for (int k = 0; k < 9; k++) {
-            const double r = block_sum_d((double)v9[k], red);
-            if (threadIdx.x == 0) atomicAdd(&MDX_VIR(dw, k), -0.5 * r);
-        }
+        // the nine virial sums in one reduction; thread k adds the k-th
+        __shared__ double red[16 * 9];
+        double d9[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) d9[k] = (double)v9[k];
+        const double r = block_sum_n<9>(d9, red);
+        if (threadIdx.x < 9) atomicAdd(&MDX_VIR(dw, threadIdx.x), -0.5 * r);
     }
 }
 
@@ -239,11 +241,13 @@ __device__ __forceinline__ void d_lincs(const int t, int comp0, int ncomp, const
         }
     }
     if (VIRIAL) {
-        __shared__ double red[16];
-        for (int k = 0; k < 9; k++) {
-            const double r = block_sum_d((double)v9[k], red);
-            if (threadIdx.x == 0) atomicAdd(&MDX_VIR(dw, k), -0.5 * r);
-        }
+        // the nine virial sums in one reduction; thread k adds the k-th
+        __shared__ double red[16 * 9];
+        double d9[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) d9[k] = (double)v9[k];
+        const double r = block_sum_n<9>(d9, red);
+        if (threadIdx.x < 9) atomicAdd(&MDX_VIR(dw, threadIdx.x), -0.5 * r);
     }
 }
 
@@ -471,7 +475,7 @@ __global__ __launch_bounds__(256) void k_ke(int n, const float4 *__restrict__ v,
                                             DevState *dw, int old_slot, int tensor)
 {
     // grid-stride: a fixed, small number of workgroups keeps the count of contended double atomics low
-    __shared__ double red[16];
+    __shared__ double red[16 * (MDX_MAX_TC + 6)];
     double keg[MDX_MAX_TC];
     double t6[6] = { 0, 0, 0, 0, 0, 0 };
 #pragma unroll
@@ -488,22 +492,21 @@ __global__ __launch_bounds__(256) void k_ke(int n, const float4 *__restrict__ v,
             t6[3] += 0.5f * m * vi.y * vi.y; t6[4] += 0.5f * m * vi.y * vi.z; t6[5] += 0.5f * m * vi.z * vi.z;
         }
     }
+    // group kinetic energies and the six tensor sums in one reduction; thread k adds the k-th
     const int ng = ntc > 0 ? ntc : 1;
+    double all[MDX_MAX_TC + 6];
 #pragma unroll
-    for (int k = 0; k < MDX_MAX_TC; k++) {
-        if (k >= ng) break;
-        const double r = block_sum_d(keg[k], red);
-        if (threadIdx.x == 0 && r != 0.0) atomicAdd(old_slot ? &dw->ekinh_old[k] : &dw->ekinh[k], r);
-    }
-    if (tensor) {
+    for (int k = 0; k < MDX_MAX_TC; k++) all[k] = keg[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) all[MDX_MAX_TC + k] = t6[k];
+    const double r = block_sum_n<MDX_MAX_TC + 6>(all, red);
+    const int t = threadIdx.x;
+    if (t < ng && r != 0.0) atomicAdd(old_slot ? &dw->ekinh_old[t] : &dw->ekinh[t], r);
+    if (tensor && t >= MDX_MAX_TC && t < MDX_MAX_TC + 6) {
         const int map[6][2] = { { 0, 0 }, { 1, 3 }, { 2, 6 }, { 4, 4 }, { 5, 7 }, { 8, 8 } };
-        for (int k = 0; k < 6; k++) {
-            const double r = block_sum_d(t6[k], red);
-            if (threadIdx.x == 0) {
-                atomicAdd(&MDX_EKT(dw, map[k][0]), 0.5 * r);   // average of two half steps
-                if (map[k][1] != map[k][0]) atomicAdd(&MDX_EKT(dw, map[k][1]), 0.5 * r);
-            }
-        }
+        const int k = t - MDX_MAX_TC;
+        atomicAdd(&MDX_EKT(dw, map[k][0]), 0.5 * r);   // average of two half steps
+        if (map[k][1] != map[k][0]) atomicAdd(&MDX_EKT(dw, map[k][1]), 0.5 * r);
     }
 }
 
