@@ -419,11 +419,13 @@ extern "C" int mdx_set_nonbonded(mdx_system *s, float rc, float rlist, float bet
     }
     if (!s->htab) MDX_CHECK(s, hipMalloc((void **)&s->htab, sizeof(float4) * MDX_GTAB_N));
     MDX_CHECK(s, hipMemcpy(s->htab, tab4.data(), sizeof(float4) * MDX_GTAB_N, hipMemcpyHostToDevice));
-    // the force kernel's table carries beta^3 g: one multiplication less per pair
+    // the force kernel's table carries beta^3 g (one multiplication less per pair), each interval as the line
+    // c0 + c1 t through its end points in the table coordinate t = r^2 N / rc^2 itself (no fractional part to take)
     const double b3 = (double)beta * beta * beta;
     for (int k = 0; k < MDX_GTAB_N; k++) {
         const double g0 = g(wmax * k / MDX_GTAB_N), g1 = g(wmax * (k + 1) / MDX_GTAB_N);
-        tab[k] = make_float2((float)(b3 * g0), (float)(b3 * (g1 - g0)));
+        const double c1 = b3 * (g1 - g0);
+        tab[k] = make_float2((float)(b3 * g0 - c1 * k), (float)c1);
     }
     if (!s->gtab) MDX_CHECK(s, hipMalloc((void **)&s->gtab, sizeof(float2) * MDX_GTAB_N));
     MDX_CHECK(s, hipMemcpy(s->gtab, tab.data(), sizeof(float2) * MDX_GTAB_N, hipMemcpyHostToDevice));

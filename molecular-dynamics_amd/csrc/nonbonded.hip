@@ -35,7 +35,7 @@ struct NbArgs {
     int do_pairs, do_excl;       // evaluate listed pairs / the Ewald correction of excluded pairs
     int dbg;                     // diagnostic ablation bits (timing experiments only)
     const float4 *htab;          // MDX_GTAB_N entries (g, step of g, h, step of h), h(w) = erf(z)/z
-    const float2 *gtab;          // MDX_GTAB_N entries beta^3 (g(w_k), g(w_k+1) - g(w_k)), w_k = beta^2 rc^2 k / MDX_GTAB_N
+    const float2 *gtab;          // MDX_GTAB_N entries (c0, c1): beta^3 g = c0 + c1 t on the k-th interval of t = r^2 MDX_GTAB_N / rc^2
     float tab_scale;             // MDX_GTAB_N / rc^2
     int dyn_split;               // log2 of the parts a unit is cut into when handed out dynamically
     int dyn;                     // rounds' worth of units at the cheap end of the list handed out dynamically (0: static deal only)
@@ -293,11 +293,11 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                     if (GENERAL && slot) fs = listed ? fs : 0.0f;      // wave-uniform: few tiles hold an excluded pair
                     float g;
                     if (ABL & 4) {
-                        // g(beta^2 r^2) by linear interpolation in a table uniform in r^2 (entry: value, step to the next):
+                        // g(beta^2 r^2) by linear interpolation in a table uniform in r^2 (entry: the interval's line c0 + c1 t):
                         // the look-up runs on the LDS pipe next to the LJ arithmetic and replaces a dozen VALU instructions
                         const float t = r2 * A.tab_scale;
                         const float2 te = gtab[(unsigned)t & (MDX_GTAB_N - 1)];
-                        g = fmaf(__builtin_amdgcn_fractf(t), te.y, te.x);      // the table holds beta^3 g
+                        g = fmaf(t, te.y, te.x);      // the table holds beta^3 g
                         fs = fmaf(-qq, g, fs);
                     } else {
                         g = (ABL & 1) ? beta2 * r2 : mdx_pmecorr(beta2 * r2);
