@@ -254,6 +254,11 @@ int mdx_dd_step_end(mdx_system *sys);
 int mdx_dd_grid(mdx_system *sys, void **grid_dev, long long *nelem);
 int mdx_dd_stream_sync(mdx_system *sys);
 int mdx_dd_state_pointers(mdx_system *sys, void **x4_dev, void **v4_dev);
+/* The handle's main stream and PME stream (hipStream_t) for callers that order their collectives on the device instead
+ * of on the host: the sum of the charge grid enqueued on (or made to wait for and be waited for by) the PME stream
+ * between mdx_dd_step_begin and mdx_dd_step_end needs no mdx_dd_wait_spread and no host synchronisation; exchanges
+ * and scalar sums go on the main stream the same way. No counterpart in the reference (single-rank mdrun). */
+int mdx_dd_streams(mdx_system *sys, void **main_stream, void **pme_stream);
 /* Quantities the domains have to agree on. Energy steps: every domain's energy terms, virial and pressure are
  * partial sums over the atoms it owns (a pair with a halo atom counts half on each side, the Ewald self term covers
  * the home atoms) and add up over the domains; the reciprocal-space energy and virial are the same on every domain,

@@ -237,6 +237,13 @@ extern "C" int mdx_dd_stream_sync(mdx_system *s)
     return MDX_OK;
 }
 
+extern "C" int mdx_dd_streams(mdx_system *s, void **main_stream, void **pme_stream)
+{
+    if (main_stream) *main_stream = (void *)s->stream;
+    if (pme_stream) *pme_stream = (void *)s->st_pme;
+    return MDX_OK;
+}
+
 // Current device pointers of positions (float4: xyz, charge) and velocities (float4: xyz, inverse mass); they
 // change with every step (double buffering), so they are valid until the next step call only.
 extern "C" int mdx_dd_state_pointers(mdx_system *s, void **x4_dev, void **v4_dev)

@@ -121,10 +121,16 @@ class Transport:
     """Collectives on device tensors; with a gloo group the tensors are staged through the host (tests)."""
 
     def __init__(self, group=None):
+        import os
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.staged = dist.is_initialized() and dist.get_backend(group) == "gloo"
+        # device-ordered collectives: RCCL work is ordered against the stream that is current when it is issued, so no host
+        # synchronisation is needed around it. MDX_DD_FORCE_COLLECTIVES=1 issues the reductions at world size 1 as well
+        # (rehearsal of that ordering on one GPU).
+        self.ordered = dist.is_initialized() and not self.staged
+        self.force = self.ordered and bool(os.environ.get("MDX_DD_FORCE_COLLECTIVES"))
 
     def all_gather(self, t: torch.Tensor):
         if self.world == 1:
@@ -135,7 +141,7 @@ class Transport:
         return [o.to(t.device) for o in out] if self.staged else out
 
     def all_reduce_sum_(self, t: torch.Tensor):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return t
         if self.staged:
             h = t.cpu()
@@ -341,6 +347,14 @@ class DecomposedWater:
                                  nstpcouple=nstpcouple, seed=seed if global_coupling else seed + self.rank)
         if self.pcoupl:
             self.pres_t = torch.as_tensor(_DevArray(self.engine.dd_pressure(), (9,), "<f8"), device=self.dev)
+        # With an RCCL transport every collective is issued with the handle's own stream current (main stream; PME stream
+        # for the charge grid): the reductions and exchanges then take their place in the handle's stream order and the
+        # host never waits for the device inside a step.
+        self.ordered = bool(getattr(self.tr, "ordered", False)) and (self.world > 1 or getattr(self.tr, "force", False))
+        if self.ordered:
+            sm, sp = self.engine.dd_streams()
+            self.st_main = torch.cuda.ExternalStream(sm, device=self.dev)
+            self.st_pme = torch.cuda.ExternalStream(sp, device=self.dev)
         self.thermostat = ref_t is not None
         self.global_coupling = bool(global_coupling)
         self.nsttcouple, self.nstcomm, self.nstcalcenergy = int(nsttcouple), int(nstcomm), int(nstcalcenergy)
@@ -435,10 +449,14 @@ class DecomposedWater:
         ns = sum(self.send_counts)
         if ns:
             self.engine.dd_pack(ns, self.send_idx.data_ptr(), self.send_buf.data_ptr())
-        self.engine.dd_stream_sync()
         send = list(torch.split(self.send_buf, self.send_counts)); recv = list(torch.split(self.recv_buf, self.recv_counts))
-        self.tr.exchange(send, recv)
-        torch.cuda.synchronize(self.dev)
+        if self.ordered:
+            with torch.cuda.stream(self.st_main):       # behind the pack, ahead of the unpack, in the main stream's order
+                self.tr.exchange(send, recv)
+        else:
+            self.engine.dd_stream_sync()
+            self.tr.exchange(send, recv)
+            torch.cuda.synchronize(self.dev)
         if self.n_halo:
             self.engine.dd_unpack(MOL_ATOMS * self.n_home, MOL_ATOMS * self.n_halo, self.recv_buf.data_ptr())
 
@@ -474,51 +492,79 @@ class DecomposedWater:
                 self.tr.all_reduce_sum_(self.ekinh_t); torch.cuda.synchronize(self.dev)
                 with self._exclusive():
                     self.engine.dd_tcouple(before_first_step=True)
+                self.engine.dd_stream_sync()
             if self.steps_since_partition >= self.nstlist:
                 say("repartition"); self.repartition()
             elif self.steps_since_partition > 0:
                 say("halo refresh"); self._refresh_halo()
-            with self._exclusive():
+            if self.ordered:
                 say("begin"); self.engine.dd_step_begin()
-                if self.world > 1:
-                    say("wait spread"); self.engine.dd_wait_spread()
-            if self.world > 1:
-                say("grid sum"); self.tr.all_reduce_sum_(self.grid_t)
-                torch.cuda.synchronize(self.dev)
-            with self._exclusive():
+                with torch.cuda.stream(self.st_pme):        # behind the spreading, ahead of the transforms
+                    say("grid sum"); self.tr.all_reduce_sum_(self.grid_t)
                 say("end"); self.engine.dd_step_end()
+            else:
+                with self._exclusive():
+                    say("begin"); self.engine.dd_step_begin()
+                    if self.world > 1:
+                        say("wait spread"); self.engine.dd_wait_spread()
+                if self.world > 1:
+                    say("grid sum"); self.tr.all_reduce_sum_(self.grid_t)
+                    torch.cuda.synchronize(self.dev)
+                with self._exclusive():
+                    say("end"); self.engine.dd_step_end()
             done = self.nsteps_done + 1
             if self.nstcalcenergy > 0 and self.nsteps_done % self.nstcalcenergy == 0:
                 self._volume_at_energy = self.volume
             if self.pcoupl and self.nsteps_done % self.nstpcouple == 0:
                 # the step left this domain's share of the pressure in the scalars: sum it, scale every domain alike, and
                 # put the share back (energies() adds the shares up itself)
-                self.engine.dd_stream_sync()
-                share = self.pres_t.clone()
-                self.tr.all_reduce_sum_(self.pres_t)
                 pdisp = self.dispersion_correction()[1]
-                if pdisp != 0.0:
-                    self.pres_t[0::4] += pdisp
-                torch.cuda.synchronize(self.dev)
-                with self._exclusive():
-                    box = self.engine.dd_pcouple()
-                self.pres_t.copy_(share); torch.cuda.synchronize(self.dev)
+                if self.ordered:
+                    with torch.cuda.stream(self.st_main):
+                        share = self.pres_t.clone()
+                        self.tr.all_reduce_sum_(self.pres_t)
+                        if pdisp != 0.0:
+                            self.pres_t[0::4] += pdisp
+                    box = self.engine.dd_pcouple()          # (waits for the main stream: the new cell comes back to the host)
+                    with torch.cuda.stream(self.st_main):
+                        self.pres_t.copy_(share)
+                else:
+                    self.engine.dd_stream_sync()
+                    share = self.pres_t.clone()
+                    self.tr.all_reduce_sum_(self.pres_t)
+                    if pdisp != 0.0:
+                        self.pres_t[0::4] += pdisp
+                    torch.cuda.synchronize(self.dev)
+                    with self._exclusive():
+                        box = self.engine.dd_pcouple()
+                    self.pres_t.copy_(share); torch.cuda.synchronize(self.dev)
                 self.box_np = np.asarray(box, dtype=np.float64)
                 self.box = torch.tensor(self.box_np, dtype=torch.float64, device=self.dev)
                 self.volume = float(abs(np.linalg.det(self.box_np)))
                 self.density = 3 * self.nmol / self.volume
             if shared_tc and done % self.nsttcouple == 0:
                 # the step left the home atoms' half-step kinetic energy in the scalars: sum, then one factor for all
-                self.engine.dd_stream_sync()
-                self.tr.all_reduce_sum_(self.ekinh_t); torch.cuda.synchronize(self.dev)
-                with self._exclusive():
+                if self.ordered:
+                    with torch.cuda.stream(self.st_main):
+                        self.tr.all_reduce_sum_(self.ekinh_t)
                     self.engine.dd_tcouple()
+                else:
+                    self.engine.dd_stream_sync()
+                    self.tr.all_reduce_sum_(self.ekinh_t); torch.cuda.synchronize(self.dev)
+                    with self._exclusive():
+                        self.engine.dd_tcouple()
             if self.nstcomm > 0 and done % self.nstcomm == 0:
-                with self._exclusive():
-                    self.engine.dd_com(0); self.engine.dd_stream_sync()
-                self.tr.all_reduce_sum_(self.com_t); torch.cuda.synchronize(self.dev)
-                with self._exclusive():
+                if self.ordered:
+                    self.engine.dd_com(0)
+                    with torch.cuda.stream(self.st_main):
+                        self.tr.all_reduce_sum_(self.com_t)
                     self.engine.dd_com(1)
+                else:
+                    with self._exclusive():
+                        self.engine.dd_com(0); self.engine.dd_stream_sync()
+                    self.tr.all_reduce_sum_(self.com_t); torch.cuda.synchronize(self.dev)
+                    with self._exclusive():
+                        self.engine.dd_com(1)
             self.steps_since_partition += 1
             self.nsteps_done += 1
 

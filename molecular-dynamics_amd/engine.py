@@ -34,7 +34,7 @@ SYMBOLS = [
     "mdx_synchronize", "mdx_get_list_stats", "mdx_pop_energy_frames", "mdx_pop_pull_records",
     "mdx_enable_kernel_timing", "mdx_get_kernel_timing", "mdx_debug_time_nonbonded", "mdx_debug_set", "mdx_debug_wave_times", "mdx_debug_stamps",
     "mdx_dd_load", "mdx_dd_pack", "mdx_dd_unpack", "mdx_dd_step_begin", "mdx_dd_wait_spread", "mdx_dd_step_end", "mdx_dd_grid",
-    "mdx_dd_stream_sync", "mdx_dd_state_pointers", "mdx_dd_set_roles", "mdx_dd_scalars", "mdx_dd_tcouple", "mdx_dd_kinetic", "mdx_dd_com", "mdx_dd_pressure", "mdx_dd_pcouple",
+    "mdx_dd_stream_sync", "mdx_dd_state_pointers", "mdx_dd_streams", "mdx_dd_set_roles", "mdx_dd_scalars", "mdx_dd_tcouple", "mdx_dd_kinetic", "mdx_dd_com", "mdx_dd_pressure", "mdx_dd_pcouple",
     "mdx_debug_time_stage", "mdx_set_step", "mdx_generate_velocities", "mdx_constrain_start", "mdx_minimize",
     "mdx_frame_ring", "mdx_capture_frame", "mdx_frame_wait",
 ]
@@ -132,6 +132,7 @@ def load_library(path: str | None = None):
     L.mdx_dd_grid.argtypes = [vp, ctypes.POINTER(vp), llp]
     L.mdx_dd_stream_sync.argtypes = [vp]
     L.mdx_dd_state_pointers.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
+    L.mdx_dd_streams.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
     L.mdx_dd_set_roles.argtypes = [vp, c_int, c_int]
     L.mdx_dd_scalars.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
     L.mdx_dd_tcouple.argtypes = [vp, c_int]; L.mdx_dd_kinetic.argtypes = [vp]; L.mdx_dd_com.argtypes = [vp, c_int]
@@ -577,6 +578,12 @@ class Engine:
         p = ctypes.c_void_p(0); n = ctypes.c_longlong(0)
         self._call("mdx_dd_grid", ctypes.byref(p), ctypes.byref(n))
         return p.value, n.value
+
+    def dd_streams(self):
+        """(main stream, PME stream) as raw hipStream_t values (for torch.cuda.ExternalStream)."""
+        a = ctypes.c_void_p(0); b = ctypes.c_void_p(0)
+        self._call("mdx_dd_streams", ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
 
     def dd_state_pointers(self):
         x = ctypes.c_void_p(0); v = ctypes.c_void_p(0)

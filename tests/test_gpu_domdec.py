@@ -60,6 +60,22 @@ def test_domains_match_single_handle(world, box):
 
 
 @pytest.mark.gpu
+def test_device_ordered_collectives_on_one_rank():
+    """The RCCL transport orders its reductions on the handle's own streams (no host synchronisation inside a step).
+    One rank with every reduction issued for real: thermostat, centre-of-mass removal, C-rescale with the dispersion
+    correction, the sum of the charge grid; the run has to reproduce the plain single handle."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dd_ordered_rank.py")], capture_output=True, text=True, timeout=170, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["box_change"] > 1e-7 and r["box_rel_diff"] < 1e-6, r
+    assert r["dx_rms"] < 5e-6 and r["dv_rel_rms"] < 1e-3, r
+    assert abs(r["pot_dd"] - r["pot_single"]) < 2e-5 * abs(r["pot_single"]) and r["pres_max_diff"] < 3.0, r
+    assert max(abs(c) for c in r["com_v"]) < 1e-5, r
+
+
+@pytest.mark.gpu
 def test_decomposed_path_at_the_tiled_million_atom_size():
     """Config 5 at its size on one GPU: the tiled water box (2x2x2 copies of the 12.5 nm dodecahedron, 1.1 M atoms)
     through the decomposed path with one rank against the plain single handle on the same state, plus the properties
