@@ -182,6 +182,8 @@ struct mdx_system {
     float rc = 1.0f, rlist = 1.1f, beta = 3.12341f;
     float4 *htab = nullptr;       // ... with h(w) = erf(z)/z beside g, for the energy kernel
     float2 *gtab = nullptr;       // MDX_GTAB_N entries of beta^3 g (Ewald correction of the force) on a uniform r^2 grid up to rc^2
+    float4 *nut_tab = nullptr;    // force table on the bits of r^2 (nonbonded.hip, k_nonbonded_f3tn): nut_n intervals from the bit pattern nut_lo
+    int nut_n = 0; unsigned nut_lo = 0; bool nut_attr_set = false;
     int nstlist = 10;
     // PME
     int K[3] = {0, 0, 0};

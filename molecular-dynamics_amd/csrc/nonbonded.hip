@@ -37,6 +37,8 @@ struct NbArgs {
     const float4 *htab;          // MDX_GTAB_N entries (g, step of g, h, step of h), h(w) = erf(z)/z
     const float2 *gtab;          // MDX_GTAB_N entries (c0, c1): beta^3 g = c0 + c1 t on the k-th interval of t = r^2 MDX_GTAB_N / rc^2
     float tab_scale;             // MDX_GTAB_N / rc^2
+    const float4 *nut;           // force table on a grid uniform in the bits of r^2 (512 intervals per binade): per interval the lines of 1/r^2 and of 1/r^3 - beta^3 g
+    unsigned nut_lo, nut_last;   // bit pattern of the table's lowest r^2, index of its last interval
     int dyn_split;               // log2 of the parts a unit is cut into when handed out dynamically
     int dyn;                     // rounds' worth of units at the cheap end of the list handed out dynamically (0: static deal only)
     long long *wave_t;           // diagnostic: per wave (start clock, end clock, wall start, wall end, units, entries)
@@ -249,8 +251,20 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                 if (TIMED) n_eval++;
                 did = true;
                 const bool listed = GENERAL ? (((exh >> c) & 1u) != 0u) : true;   // false: excluded pair, Ewald correction only
-                const float rinv = __frsqrt_rn(r2);
-                const float rinv2 = rinv * rinv;
+                // NUT: 1/r^2 and the Coulomb force factor 1/r^3 - beta^3 g both come from one table entry addressed by the
+                // leading bits of r^2 (lines in r^2 itself), so the pair needs no reciprocal square root, which costs the
+                // vector unit four issue slots
+                constexpr bool NUT = !ENERGY && (ABL & 256) != 0;
+                float rinv = 0.0f, rinv2, cnut = 0.0f;
+                if (NUT) {
+                    const unsigned k = min((__float_as_uint(r2) - A.nut_lo) >> 14, A.nut_last);
+                    const float4 te = ((const float4 *)gtab)[k];
+                    rinv2 = fmaf(te.y, r2, te.x);
+                    cnut = fmaf(te.w, r2, te.z);
+                } else {
+                    rinv = __frsqrt_rn(r2);
+                    rinv2 = rinv * rinv;
+                }
                 float hs_c, se_c;
                 if (ILDS) { const float2 li = myilj[c * 8 + ti]; hs_c = li.x; se_c = li.y; } else { hs_c = hsi[c]; se_c = sei[c]; }
                 const float sg = hs_c + lj.x;
@@ -287,6 +301,11 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                         fs = listed ? fs : -qq * beta3 * g;
                         e_ex = -qq * beta * fmaf(g, w_, MDX_2_SQRTPI * ex2);
                     }
+                } else if (NUT) {
+                    // t6 (12 s6 - 6) / r^2 + qq (1/r^3 - beta^3 g); an excluded pair keeps -qq beta^3 g = qq (c - 1/r^3)
+                    fs *= rinv2;
+                    if (GENERAL && slot) fs = listed ? fmaf(qq, cnut, fs) : qq * (cnut - rinv2 * __builtin_sqrtf(rinv2));
+                    else fs = fmaf(qq, cnut, fs);
                 } else {
                     // (t6 (12 s6 - 6) + qq/r) / r^2 - qq beta^3 g; an excluded pair keeps only the last term
                     fs = fmaf(qq, rinv, fs) * rinv2;
@@ -470,6 +489,16 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __syncthreads();
     nb_body<false, false, 4 | 16 | 128>(A, (const float2 *)tab4, ilj);
 }
+// The same with the force table on the bits of r^2 (no reciprocal square root per pair); the table's size follows the cutoff.
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_f3tn(NbArgs A)
+{
+    extern __shared__ float4 dyn4[];
+    float4 *tab4 = dyn4;
+    float2 *ilj = (float2 *)(dyn4 + A.nut_last + 1);
+    for (unsigned k = threadIdx.x; k <= A.nut_last; k += 768) tab4[k] = A.nut[k];
+    __syncthreads();
+    nb_body<false, false, 16 | 256>(A, (const float2 *)tab4, ilj);
+}
 // The same with the run-time switches that leave out the force atomics (timing experiments: mdx_debug_set key 2, bits
 // 0x20000 and 0x40000); the production kernel does not carry their tests.
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_f3tl_abl(NbArgs A)
@@ -566,6 +595,7 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
     A.wave_t = s->nb_wave_t;
     A.dyn = s->nb_dyn; A.dyn_split = s->nb_dyn_split;
     A.htab = s->htab; A.gtab = s->gtab; A.tab_scale = (float)MDX_GTAB_N / (s->rc * s->rc);
+    A.nut = s->nut_tab; A.nut_lo = s->nut_lo; A.nut_last = s->nut_n > 0 ? (unsigned)s->nut_n - 1u : 0u;
     A.do_pairs = (terms & MDX_F_NONBONDED) ? 1 : 0;
     A.do_excl = ((terms & MDX_F_EXCL) && s->beta > 0.0f) ? 1 : 0;
     if (!A.do_pairs && !A.do_excl) return MDX_OK;
@@ -618,7 +648,16 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
     // serves, a marker recorded behind it would fire microseconds later)
     s->nb_done_event = nullptr;
     if (s->rotate_streams == 2) { if (!ev_b) ev_b = s->ev_nbdone; s->nb_done_event = ev_b; }
-    hipExtLaunchKernelGGL(kern, grid, block, 0, s->stream, ev_a, ev_b, 0, A);
+    size_t dyn_lds = 0;
+    if (kern == k_nonbonded_f3tl && (s->dbg & 0x10000000) && s->nut_tab) {
+        kern = k_nonbonded_f3tn;
+        dyn_lds = sizeof(float4) * (size_t)s->nut_n + sizeof(float2) * 12 * 64;
+        if (dyn_lds > 64 * 1024 && !s->nut_attr_set) {
+            MDX_CHECK(s, hipFuncSetAttribute((const void *)k_nonbonded_f3tn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
+            s->nut_attr_set = true;
+        }
+    }
+    hipExtLaunchKernelGGL(kern, grid, block, dyn_lds, s->stream, ev_a, ev_b, 0, A);
     MDX_CHECK(s, hipGetLastError());
     return MDX_OK;
 }
