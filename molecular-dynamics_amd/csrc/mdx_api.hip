@@ -93,7 +93,8 @@ extern "C" mdx_system *mdx_create(int device, int natoms)
               hipEventCreateWithFlags(&s->ev_pme, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_bond, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_spread, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
-              hipEventCreateWithFlags(&s->ev_nbdone, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
+              hipEventCreateWithFlags(&s->ev_nbdone, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
+              hipEventCreateWithFlags(&s->ev_tc, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
     s->own_streams[0] = s->stream; s->own_streams[1] = s->st_pme; s->own_streams[2] = s->st_bond;
     // MDX_STREAMS=1: every kernel of the handle on one stream (diagnostic; three streams are the default)
     if (const char *e = getenv("MDX_STREAMS")) if (atoi(e) == 1 && ok) (void)mdx_set_stream_mode(s, 1);
@@ -158,6 +159,7 @@ extern "C" void mdx_destroy(mdx_system *s)
     if (s->ev_bond) (void)hipEventDestroy(s->ev_bond);
     if (s->ev_spread) (void)hipEventDestroy(s->ev_spread);
     if (s->ev_nbdone) (void)hipEventDestroy(s->ev_nbdone);
+    if (s->ev_tc) (void)hipEventDestroy(s->ev_tc);
     for (hipStream_t st : s->own_streams) if (st) (void)hipStreamDestroy(st);
     delete s;
 }
@@ -973,7 +975,20 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
         if ((rc = mdx_launch_finish_energy(s, do_ener ? next_energy_frame(s) : nullptr, do_pc && !s->dd_on))) return rc;
         if (do_ener) frame_steps(s).push_back(step);
     }
-    if (s->ntc > 0 && ((step + 1) % s->nsttcouple == 0)) {
+    const bool comm_now = s->nstcomm > 0 && ((step + 1) % s->nstcomm == 0);
+    if (s->ntc > 0 && ((step + 1) % s->nsttcouple == 0) && phase == 0 && !need_vir && !comm_now && !s->dd_on && !s->one_stream &&
+        s->tc_on_side && more) {
+        // The thermostat's kinetic energy and the factor for the coming steps are needed by the next update only: they run
+        // on the bonded stream beside the next step's nonbonded kernel instead of in front of it (22 us of main-stream time
+        // every nsttcouple steps). The velocities they read are final once the update has completed; nothing on the main
+        // stream changes them before the next update (centre-of-mass removal and pressure coupling steps keep the old place).
+        if (!forked_early) {
+            MDX_CHECK(s, hipEventRecord(s->ev_tc, s->stream));
+            MDX_CHECK(s, hipStreamWaitEvent(s->st_bond, s->ev_tc, 0));
+        }
+        if ((rc = mdx_launch_ke(s, false, false, s->st_bond, true))) return rc;
+        if ((rc = mdx_launch_tcouple(s, s->st_bond, true))) return rc;
+    } else if (s->ntc > 0 && ((step + 1) % s->nsttcouple == 0)) {
         if (!need_vir) {
             if ((rc = mdx_launch_clear(s, false, true, false))) return rc;
             if ((rc = mdx_launch_ke(s, false, false))) return rc;

@@ -32,6 +32,7 @@ struct DevState {
     double vir[9];                // -1/2 sum r (x) F of all force terms + constraints
     double ekinh_old[MDX_MAX_TC]; // half-step kinetic energy per T-group before the update
     double ekinh[MDX_MAX_TC];     // ... after the update
+    double ekinh_tc[MDX_MAX_TC];  // ... after the update, for the thermostat when it runs beside the next step (zeroed by its reader)
     double ekin_tensor[9];        // average of the two half-step tensors (energy steps)
     double lambda[MDX_MAX_TC];    // V-rescale scaling factor for the coming step
     double therm_integral[MDX_MAX_TC];
@@ -213,6 +214,8 @@ struct mdx_system {
     std::vector<int> h_settle; std::vector<int2> h_cij; std::vector<int> h_cstart;   // host copies of the constraint topology
     int fused_plan = 0;           // 0: not built yet, 1: usable, -1: this topology needs the separate kernels
     int fused_update = 1;         // use it on steps without virial (mdx_debug_set key 12)
+    int tc_on_side = 0;           // thermostat kernels of plain steps on the bonded stream, beside the next step: measured neutral, off (mdx_debug_set key 13)
+    hipEvent_t ev_tc = nullptr;   // "velocities of this step are final" for the bonded stream when no fork event follows the update
     int *comp_atom_start = nullptr, *comp_atoms = nullptr, *comp_local = nullptr, *free_atoms = nullptr; int nfree = 0;
     // integration / coupling
     float dt = 0.002f;
@@ -288,12 +291,11 @@ int mdx_launch_constrain(mdx_system *s, float inv_dt, bool virial, int lincs_ite
 int mdx_fused_plan(mdx_system *s);
 int mdx_launch_update_fused(mdx_system *s, bool do_tc, bool do_pr, bool write_sorted, bool fork_signal);
 void mdx_frames_free(mdx_system *s);
-int mdx_launch_ke(mdx_system *s, bool old_slot, bool tensor, hipStream_t st = nullptr);
+int mdx_launch_ke(mdx_system *s, bool old_slot, bool tensor, hipStream_t st = nullptr, bool tc_slot = false);
 int mdx_launch_comm_phase(mdx_system *s, int phase);
 int mdx_launch_clear(mdx_system *s, bool energies, bool ekin_new, bool ekin_old);
-int mdx_launch_tcouple(mdx_system *s);
+int mdx_launch_tcouple(mdx_system *s, hipStream_t st = nullptr, bool tc_slot = false);
 int mdx_launch_clear(mdx_system *s, bool energies, bool ekin_new, bool ekin_old);
-int mdx_launch_tcouple(mdx_system *s);
 int mdx_launch_pcouple(mdx_system *s);
 int mdx_launch_comm(mdx_system *s);
 int mdx_launch_finish_energy(mdx_system *s, double *frame = nullptr, bool with_pcouple = false);

@@ -736,6 +736,7 @@ extern "C" int mdx_debug_set(mdx_system *s, int key, int value)
     if (key == 5) { s->early_fork = value; return MDX_OK; }
     if (key == 4 && value >= 0 && value <= 3) { s->nb_dyn_split = value; return MDX_OK; }
     if (key == 11) { s->count_pairs_steps = s->count_pairs = value != 0; return MDX_OK; }     // energy steps of mdx_step count the pairs inside the cutoff
+    if (key == 13) { s->tc_on_side = value != 0; return MDX_OK; }       // thermostat kernels of plain steps on the bonded stream
     if (key == 12) { s->fused_update = value != 0; return MDX_OK; }     // leap-frog + constraints (+ next sorted coordinates) in one launch
     if (key == 10) {      // streams per handle: 1 (every kernel in one stream's order) or 3
         if (value != 1 && value != 3) { s->err = "mdx_debug_set: key 10 takes 1 or 3"; return MDX_ERR_ARG; }

@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void k_ke(int n, const float4 *__restrict__ v,
     for (int k = 0; k < 6; k++) all[MDX_MAX_TC + k] = t6[k];
     const double r = block_sum_n<MDX_MAX_TC + 6>(all, red);
     const int t = threadIdx.x;
-    if (t < ng && r != 0.0) atomicAdd(old_slot ? &dw->ekinh_old[t] : &dw->ekinh[t], r);
+    if (t < ng && r != 0.0) atomicAdd(old_slot == 2 ? &dw->ekinh_tc[t] : (old_slot ? &dw->ekinh_old[t] : &dw->ekinh[t]), r);
     if (tensor && t >= MDX_MAX_TC && t < MDX_MAX_TC + 6) {
         const int map[6][2] = { { 0, 0 }, { 1, 3 }, { 2, 6 }, { 4, 4 }, { 5, 7 }, { 8, 8 } };
         const int k = t - MDX_MAX_TC;
@@ -512,13 +512,15 @@ __global__ __launch_bounds__(256) void k_ke(int n, const float4 *__restrict__ v,
 
 // V-rescale (Bussi, Donadio, Parrinello 2007): one thread draws the new kinetic energy of every
 // group from the half-step kinetic energy just computed and stores lambda for the coming step.
+// tc_slot: the kinetic energy comes from the accumulator of the side-stream thermostat, which is left zeroed for the next use.
 __global__ void k_tcouple(DevState *dw, int ntc, const double *ref_t, const double *tau_t, const double *ndf,
-                          double dt_tc, unsigned long long seed, long long step)
+                          double dt_tc, unsigned long long seed, long long step, int tc_slot)
 {
     MDX_STAMP(dw, 15);
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     for (int g = 0; g < ntc; g++) {
-        const double ek = dw->ekinh[g];
+        const double ek = tc_slot ? dw->ekinh_tc[g] : dw->ekinh[g];
+        if (tc_slot) dw->ekinh_tc[g] = 0.0;
         double lam = 1.0;
         if (ek > 0.0 && tau_t[g] > 0.0 && ndf[g] > 0.0) {
             const double ekref = 0.5 * ndf[g] * MDX_BOLTZ * ref_t[g];
@@ -855,10 +857,10 @@ int mdx_launch_constrain(mdx_system *s, float inv_dt, bool virial, int lincs_ite
     return MDX_OK;
 }
 
-int mdx_launch_ke(mdx_system *s, bool old_slot, bool tensor, hipStream_t st)
+int mdx_launch_ke(mdx_system *s, bool old_slot, bool tensor, hipStream_t st, bool tc_slot)
 {
     const int nb = std::min((s->n + 255) / 256, 128);
-    hipLaunchKernelGGL(k_ke, dim3(nb), dim3(256), 0, st ? st : s->stream, s->n, s->v, s->tcgrp, s->ntc, s->d, old_slot ? 1 : 0, tensor ? 1 : 0);
+    hipLaunchKernelGGL(k_ke, dim3(nb), dim3(256), 0, st ? st : s->stream, s->n, s->v, s->tcgrp, s->ntc, s->d, tc_slot ? 2 : (old_slot ? 1 : 0), tensor ? 1 : 0);
     MDX_CHECK(s, hipGetLastError());
     return MDX_OK;
 }
@@ -890,11 +892,11 @@ int mdx_launch_clear(mdx_system *s, bool energies, bool ekin_new, bool ekin_old)
     return MDX_OK;
 }
 
-int mdx_launch_tcouple(mdx_system *s)
+int mdx_launch_tcouple(mdx_system *s, hipStream_t st, bool tc_slot)
 {
     if (s->ntc <= 0) return MDX_OK;
-    hipLaunchKernelGGL(k_tcouple, dim3(1), dim3(64), 0, s->stream, s->d, s->ntc, s->d_tc, s->d_tc + MDX_MAX_TC,
-                       s->d_tc + 2 * MDX_MAX_TC, (double)s->nsttcouple * s->dt, (unsigned long long)s->seed, s->step);
+    hipLaunchKernelGGL(k_tcouple, dim3(1), dim3(64), 0, st ? st : s->stream, s->d, s->ntc, s->d_tc, s->d_tc + MDX_MAX_TC,
+                       s->d_tc + 2 * MDX_MAX_TC, (double)s->nsttcouple * s->dt, (unsigned long long)s->seed, s->step, tc_slot ? 1 : 0);
     MDX_CHECK(s, hipGetLastError());
     return MDX_OK;
 }
