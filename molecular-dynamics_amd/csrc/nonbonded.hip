@@ -642,7 +642,7 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
         else if (s->dbg & 0x100000) kern = k_nonbonded_f3_abl1;
         else if (s->dbg & 0x200000) kern = k_nonbonded_f3_abl2;
         else if ((s->dbg & 0x400000) || !s->gtab) kern = k_nonbonded_f3;
-        else { kern = (s->dbg & 0x800000) ? k_nonbonded_f3t128 : ((s->dbg & 0x4000000) ? k_nonbonded_f3t : ((s->dbg & 0x60000) ? k_nonbonded_f3tl_abl : ((s->dbg & 0x8000000) ? k_nonbonded_f3tlp : k_nonbonded_f3tl))); grid = dim3(256); block = dim3(768); }
+        else { kern = (s->dbg & 0x800000) ? k_nonbonded_f3t128 : ((s->dbg & 0x4000000) ? k_nonbonded_f3t : ((s->dbg & 0x60000) ? k_nonbonded_f3tl_abl : ((s->dbg & 0x20000000) ? k_nonbonded_f3tlp : k_nonbonded_f3tl))); grid = dim3(256); block = dim3(768); }
     } else if (wv == 4 && s->gtab && !(s->dbg & 0x400000)) { kern = k_nonbonded_f4tl4; grid = dim3(256); block = dim3(1024); }
     // (rotate_streams == 2: the update waits for this launch on another stream; the kernel's own completion signal
     // serves, a marker recorded behind it would fire microseconds later)

@@ -6,7 +6,7 @@ s = synth.pseudo_complex(d=6.0, protein_radius=1.0, n_active=60, ligand_offset=1
 s.x = s.x.astype(np.float32).astype(np.float64)
 v0 = s.v.astype(np.float32).astype(np.float64)
 res = []
-bits_list = [0] + ([int(a, 0) for a in sys.argv[1:]] or [0x8000000])
+bits_list = [0] + ([int(a, 0) for a in sys.argv[1:]] or [0x20000000])
 for bits in bits_list:
     e = eng.Engine(s, rc=1.0, nstcalcenergy=0, nstcomm=0, dt=0.002)
     e.debug_set(2, bits)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything the committed profiles of this round are made from (GPU box, repository root): the GPU tests, the smoke
+# Everything the committed profiles are made from (GPU box, repository root): the GPU tests, the smoke
 # entry, the default bench line, a longer bench, the kernel trace statistics of the bench command, the in-kernel step
 # timeline, and the counter passes of the nonbonded kernel. Each GPU step has its own time limit; the script stops at
 # the first failure.
