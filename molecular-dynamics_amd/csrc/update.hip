@@ -548,15 +548,31 @@ __device__ void pcouple_scalars(DevState *dw, int kind, double tau_p, double ref
 __global__ void k_finish_energy(DevState *dw, int ntc, double ndf_total, int dispcorr, double c6avg, int natoms,
                                 double rc, double q2sum, double beta, int have_pme, double *__restrict__ frame, PcoupleArgs pc)
 {
-    // fold the replicated accumulators (one quantity per thread), then thread 0 finishes
+    // Fold the replicated accumulators through LDS: lane r loads every quantity of replica r (independent loads, one
+    // memory round trip for all of them) and stores them transposed; lane k then sums the 64 replicas of quantity k from
+    // LDS. (One thread per quantity walking through the replicas in global memory took 64 dependent loads, 12 of the
+    // 13 us of this launch; butterfly sums of 36 doubles over the wave take as long.) One wave per launch.
     {
-        const int t = threadIdx.x;
-        if (t < MDX_E_N) { double a = 0.0; for (int r = 0; r < MDX_NREP; r++) a += dw->ener_rep[r][t]; dw->ener[t] += a; }
-        else if (t < MDX_E_N + 9) { const int k = t - MDX_E_N; double a = 0.0; for (int r = 0; r < MDX_NREP; r++) a += dw->vir_rep[r][k]; dw->vir[k] += a; }
-        else if (t < MDX_E_N + 18) { const int k = t - MDX_E_N - 9; double a = 0.0; for (int r = 0; r < MDX_NREP; r++) a += dw->ekt_rep[r][k]; dw->ekin_tensor[k] += a; }
-        else if (t < MDX_E_N + 20) {
-            const int k = t - MDX_E_N - 18; unsigned long long a = 0;
-            for (int r = 0; r < MDX_NREP; r++) a += dw->npairs_rep[r][k];
+        constexpr int NQ = MDX_E_N + 18;
+        static_assert(NQ <= 64, "one lane per folded quantity");
+        __shared__ double fold[NQ * 65];
+        __shared__ unsigned long long foldn[2 * 64];
+        const int t = threadIdx.x & 63;
+#pragma unroll
+        for (int k = 0; k < MDX_E_N; k++) fold[k * 65 + t] = dw->ener_rep[t][k];
+#pragma unroll
+        for (int k = 0; k < 9; k++) { fold[(MDX_E_N + k) * 65 + t] = dw->vir_rep[t][k]; fold[(MDX_E_N + 9 + k) * 65 + t] = dw->ekt_rep[t][k]; }
+        foldn[t] = dw->npairs_rep[t][0]; foldn[64 + t] = dw->npairs_rep[t][1];
+        __syncthreads();
+        if (t < NQ) {
+            double a = 0.0;
+            for (int r = 0; r < MDX_NREP; r++) a += fold[t * 65 + r];
+            if (t < MDX_E_N) dw->ener[t] += a;
+            else if (t < MDX_E_N + 9) dw->vir[t - MDX_E_N] += a;
+            else dw->ekin_tensor[t - MDX_E_N - 9] += a;
+        } else if (t < NQ + 2) {
+            const int k = t - NQ; unsigned long long a = 0;
+            for (int r = 0; r < MDX_NREP; r++) a += foldn[k * 64 + r];
             if (k == 0) dw->npairs_rc += a; else dw->npairs_lj += a;
         }
     }
