@@ -510,15 +510,17 @@ __global__ __launch_bounds__(256) void k_ke(int n, const float4 *__restrict__ v,
     }
 }
 
-// V-rescale (Bussi, Donadio, Parrinello 2007): one thread draws the new kinetic energy of every
-// group from the half-step kinetic energy just computed and stores lambda for the coming step.
+// V-rescale (Bussi, Donadio, Parrinello 2007): one thread per group draws the group's new kinetic energy
+// from the half-step kinetic energy just computed and stores lambda for the coming step.
 // tc_slot: the kinetic energy comes from the accumulator of the side-stream thermostat, which is left zeroed for the next use.
 __global__ void k_tcouple(DevState *dw, int ntc, const double *ref_t, const double *tau_t, const double *ndf,
                           double dt_tc, unsigned long long seed, long long step, int tc_slot)
 {
     MDX_STAMP(dw, 15);
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (int g = 0; g < ntc; g++) {
+    // one thread per group (the groups' draws are independent streams)
+    if (blockIdx.x != 0 || (int)threadIdx.x >= ntc) return;
+    {
+        const int g = threadIdx.x;
         const double ek = tc_slot ? dw->ekinh_tc[g] : dw->ekinh[g];
         if (tc_slot) dw->ekinh_tc[g] = 0.0;
         double lam = 1.0;
