@@ -988,6 +988,10 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
         }
         if ((rc = mdx_launch_ke(s, false, false, s->st_bond, true))) return rc;
         if ((rc = mdx_launch_tcouple(s, s->st_bond, true))) return rc;
+    } else if (s->ntc > 0 && ((step + 1) % s->nsttcouple == 0) && !need_vir && !s->dd_on) {
+        // the thermostat's own accumulator, which the kernel that draws the factor leaves zeroed: no clearing launch
+        if ((rc = mdx_launch_ke(s, false, false, nullptr, true))) return rc;
+        if ((rc = mdx_launch_tcouple(s, nullptr, true))) return rc;
     } else if (s->ntc > 0 && ((step + 1) % s->nsttcouple == 0)) {
         if (!need_vir) {
             if ((rc = mdx_launch_clear(s, false, true, false))) return rc;
