@@ -228,8 +228,9 @@ def main():
         if not os.environ.get("MDX_BENCH_NO_FIRST_COLLECTIVE"):
             first = torch.ones(1, device="cuda"); dist.all_reduce(first); torch.cuda.synchronize()
     elif use_dist:
-        # Replicas exchange nothing while they run: their one collective (the work curves / final energies, RCCL) comes
-        # after the timed region. The RCCL communicator is therefore left to be created by that first collective, and the
+        # Replicas exchange nothing while they run: the SMD ensemble's one collective (the work curves, RCCL) comes after
+        # the timed region, production replicas have none. The RCCL communicator is therefore left to be created by that
+        # first collective (if any), and the
         # barriers and the wall-time maximum around the timed region go through a host-side (gloo) group: a process that
         # merely holds an initialised RCCL communicator runs this engine's three-stream step a third slower (662 against
         # 982 ns/day measured on one MI355X; the kernels take the same time, the hand-overs between the streams do not).
@@ -361,9 +362,8 @@ def main():
                    work_final_rank0=float(rec[-1, 3]) if len(rec) else None,
                    work_final_all=[float(w) for w in allw[:, -1]] if len(rec) else None,
                    jarzynski_dF_final=float(dF[-1]) if len(dF) else None)
-    elif use_dist:
-        # replicas only: one tiny RCCL all-gather of the final potential energies (no data-path collective)
-        allw = ensemble.gather_work(np.array([frames[-1, 2 + eng.E["POT"]]]))
+    # (production replicas exchange nothing at all: no collective is invented for them, and the RCCL communicator of the
+    # process group is never created; the SMD ensemble's one all-gather above is the path's real exchange)
     ns_day = dt * args.steps * 86400.0 / elapsed_max / 1000.0 * world
     out = None
     if rank == 0:
