@@ -451,6 +451,53 @@ def pull_distance(x, box, mass, g1, g2, pbc1=None, pbc2=None):
     return r, dr / r, coms[0], coms[1]
 
 
+def pull_forces(x, box, mass, g1, g2, type="constant-force", k=500.0, rate=0.0, t=0.0, init=0.0,
+                dim=(1, 1, 1), pbc1=None, pbc2=None):
+    """The COM pull between two groups, everything `gmx mdrun` derives from one configuration for
+    `pull = yes`, `pull_ncoords = 1`, `pull_coord1_geometry = distance` (/root/reference/mdp/pull_short.mdp:36-46):
+
+    * value r = |dr| with dr the minimum image of COM2 - COM1 restricted to `pull_coord1_dim`;
+    * scalar force along dr: constant-force f = -k (`pull_coord1_k` is minus the force, so k = 500 attracts,
+      pull_short.mdp:41,46); umbrella f = -k (r - r_ref) with r_ref = init + rate t
+      (the constant-velocity variant, /root/reference/config.yaml:38-39);
+    * per-atom forces: group 2 gets +f rhat m_i / M_2, group 1 gets -f rhat m_i / M_1;
+    * potential energy k r (constant force) or k/2 (r - r_ref)^2 (umbrella);
+    * virial -1/2 sum_i x_i (x) f_i = -1/2 dr (x) (f rhat).
+
+    `init` is the reference value at t = 0 (with `pull_coord1_start = yes` the caller adds the value of the
+    starting configuration). Returns a dict with r, rhat, f, ref, epot, forces (N, 3), virial (3, 3), com1, com2."""
+    x = np.asarray(x, dtype=np.float64)
+    mass = np.asarray(mass, dtype=np.float64)
+    r_full, _, c1, c2 = pull_distance(x, box, mass, g1, g2, pbc1, pbc2)
+    dr = min_image(box, (c2 - c1)[None, :])[0] * np.asarray(dim, dtype=np.float64)
+    r = float(np.linalg.norm(dr))
+    rhat = dr / r if r > 0 else np.zeros(3)
+    if type == "constant-force":
+        ref, f, epot = 0.0, -float(k), float(k) * r
+    elif type == "umbrella":
+        ref = float(init) + float(rate) * float(t)
+        f, epot = -float(k) * (r - ref), 0.5 * float(k) * (r - ref) ** 2
+    else:
+        raise ValueError(type)
+    forces = np.zeros_like(x)
+    g1 = np.asarray(g1); g2 = np.asarray(g2)
+    forces[g1] -= (mass[g1] / mass[g1].sum())[:, None] * (f * rhat)[None, :]
+    forces[g2] += (mass[g2] / mass[g2].sum())[:, None] * (f * rhat)[None, :]
+    return dict(r=r, rhat=rhat, f=f, ref=ref, epot=epot, forces=forces, virial=-0.5 * np.outer(dr, f * rhat),
+                com1=c1, com2=c2)
+
+
+def pull_work(type, k, rate, dt, r, f):
+    """The discrete work sums the engine's pull records carry, from the series of values r[n] and scalar forces
+    f[n] at consecutive steps: constant force W[n] = sum_{m<=n} f (r[m] - r[m-1]) = -k (r[n] - r[0]);
+    umbrella with a moving reference W[n] = sum_{m<=n} f[m] rate dt (the work of the trap, integral of F v dt with
+    v = `rate`; its sign convention follows the force column of `pullf.xvg`, /root/reference/scripts/analyze_smd_trajectory.py:56)."""
+    r = np.asarray(r, dtype=np.float64); f = np.asarray(f, dtype=np.float64)
+    if type == "constant-force":
+        return -float(k) * (r - r[0])
+    return np.cumsum(f * float(rate) * float(dt))
+
+
 def md_step(s, v, rc, beta, grid, dt, nthreads=4, lam=None, extra_force=None):
     """One leap-frog step with all force terms, SETTLE and LINCS: the per-step work of `gmx mdrun` for
     `integrator = md`. `lam` (per atom, or None) is the V-rescale factor of the atom's T-coupling group: it scales

@@ -43,7 +43,9 @@ def test_nonbonded_forces_energies_virial(which, eng_water, eng_complex, small_w
     assert np.abs(v - o["vir"]).max() < 1e-4 * np.abs(o["vir"]).max()
     # pair count from the kernel equals the oracle's exact count
     st = e.list_stats()
-    assert st["cluster_pairs"] * 64 >= o["npairs"]
+    # (a pair whose float32 and float64 r^2 fall on different sides of rc^2 may differ: none or a couple at this size)
+    assert abs(st["pairs_within_rc"] - o["npairs"]) <= 2
+    assert st["cluster_pairs"] * 64 >= st["pairs_within_rc"]
 
 
 @pytest.mark.parametrize("which", ["water", "complex"])

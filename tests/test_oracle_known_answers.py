@@ -223,6 +223,56 @@ def test_pull_distance_across_boundary():
     assert np.allclose(u, (com2 - com1) / r)
 
 
+@pytest.mark.parametrize("kind", ["constant-force", "umbrella"])
+def test_pull_forces_closed_forms(kind):
+    """The pull restatement against what its definition fixes: force = -dE/dx (finite differences of the pull energy),
+    virial = -1/2 sum x (x) f over the intact (unwrapped) groups, the two groups' forces opposite and equal, the
+    mass-weighted distribution, and the sign convention of /root/reference/mdp/pull_short.mdp:41,46 (k = 500 with
+    constant-force attracts)."""
+    box = synth.dodecahedron_box(4.0)
+    rng = np.random.default_rng(16)
+    c1 = np.array([0.1, 0.1, 0.1]); c2 = c1 + np.array([-0.5, 0.3, -0.4])
+    x = np.concatenate([c1 + rng.normal(scale=0.1, size=(10, 3)), c2 + rng.normal(scale=0.1, size=(6, 3))])
+    m = rng.uniform(1, 16, size=16)
+    g1, g2 = np.arange(10), np.arange(10, 16)
+    kw = dict(type=kind, k=500.0, rate=-0.1, t=2.0, init=0.9)
+    xs = x + rng.integers(-1, 2, size=(16, 3)) @ box          # atoms scattered over periodic images
+    o = R.pull_forces(xs, box, m, g1, g2, **kw)
+    com1 = (m[g1, None] * x[g1]).sum(0) / m[g1].sum(); com2 = (m[g2, None] * x[g2]).sum(0) / m[g2].sum()
+    r = np.linalg.norm(com2 - com1)
+    assert abs(o["r"] - r) < 1e-12
+    if kind == "constant-force":
+        assert o["f"] == -500.0 and abs(o["epot"] - 500.0 * r) < 1e-9
+    else:
+        assert abs(o["ref"] - 0.7) < 1e-15
+        assert abs(o["f"] + 500.0 * (r - 0.7)) < 1e-9 and abs(o["epot"] - 250.0 * (r - 0.7) ** 2) < 1e-9
+    F2 = o["forces"][g2].sum(0); F1 = o["forces"][g1].sum(0)
+    assert np.allclose(F1, -F2, atol=1e-12) and np.allclose(F2, o["f"] * (com2 - com1) / r, atol=1e-9)
+    assert np.allclose(o["forces"][g2], (m[g2] / m[g2].sum())[:, None] * F2[None, :], atol=1e-12)
+    # an attractive force on group 2 points from COM2 towards COM1
+    if kind == "constant-force":
+        assert F2 @ (com1 - com2) > 0
+    assert np.allclose(o["virial"], -0.5 * np.einsum("ia,ib->ab", x, o["forces"]), atol=1e-9)
+    h = 1e-6
+    for a in (0, 7, 12, 15):
+        for d in range(3):
+            xp = xs.copy(); xp[a, d] += h; xm = xs.copy(); xm[a, d] -= h
+            de = (R.pull_forces(xp, box, m, g1, g2, **kw)["epot"] - R.pull_forces(xm, box, m, g1, g2, **kw)["epot"]) / (2 * h)
+            assert abs(-de - o["forces"][a, d]) < 1e-5 * max(1.0, abs(o["f"]))
+
+
+def test_pull_forces_respect_dim_and_work_sums():
+    box = np.diag([3.0, 3.0, 3.0])
+    x = np.array([[0.2, 0.2, 0.2], [2.9, 0.5, 1.0]])
+    m = np.array([12.0, 16.0])
+    o = R.pull_forces(x, box, m, [0], [1], type="umbrella", k=1000.0, init=0.2, dim=(1, 0, 0))
+    assert abs(o["r"] - 0.3) < 1e-12 and np.allclose(o["rhat"], [-1, 0, 0])    # across the x face, y and z ignored
+    assert np.allclose(o["forces"][1], [+100.0, 0, 0]) and np.allclose(o["forces"][0], [-100.0, 0, 0])
+    r = np.array([1.0, 0.9, 0.7]); f = np.array([-500.0] * 3)
+    assert np.allclose(R.pull_work("constant-force", 500.0, 0.0, 0.001, r, f), [0.0, 50.0, 150.0])
+    assert np.allclose(R.pull_work("umbrella", 1000.0, -0.1, 0.001, r, np.array([0.0, -10.0, -30.0])), [0.0, 1e-3, 4e-3])
+
+
 # ------------------------------------------------------------------ random streams and coupling restatements
 def test_philox_known_answer_vectors():
     """Philox4x32-10 against the known-answer vectors published with the Random123 library (kat_vectors)."""
