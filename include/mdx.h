@@ -205,13 +205,15 @@ int mdx_frame_wait(mdx_system *sys, int slot, const float **x, const float **v, 
  * the pair list). Results via mdx_get_forces / mdx_get_energies / mdx_get_virial. */
 int mdx_compute_forces(mdx_system *sys, unsigned terms);
 int mdx_get_forces(mdx_system *sys, float *f);          /* natoms*3 */
-/* mdx_get_forces for callers that cannot allocate device memory (code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc). No counterpart in the reference. Same result as mdx_get_forces, which
- * stages the merged forces in a buffer it allocates and frees per call; this one stages them in a fixed array that
- * is part of the library's code object (12 MiB per GPU, held until the process ends) and calls no hipMalloc, hipFree
- * or other allocating routine. Limit: 1 048 576 atoms (MDX_ERR_OVERFLOW above that). `f` is a host buffer of
- * natoms*3 floats; pass pinned memory where the runtime's own staging of pageable copies is unwanted. Every handle
- * on one GPU shares the array: calls that overlap on one GPU (from several threads or handles) race. */
+/* mdx_get_forces for callers that cannot allocate device memory (tight serving loops, harnesses that forbid
+ * hipMalloc). No counterpart in the reference. Same result as mdx_get_forces, which stages the merged forces in a
+ * buffer it allocates and frees per call; this one stages them in a fixed array that is part of the library's code
+ * object (12 MiB per GPU, held until the process ends) and calls no hipMalloc, hipFree or other allocating routine.
+ * It synchronises the handle's stream and copies to the host, so it is not a call to make while a stream is being
+ * captured into a graph. Limits: 1 048 576 atoms (MDX_ERR_OVERFLOW above that); device indices 0 .. 63
+ * (MDX_ERR_UNSUPPORTED above that). `f` is a host buffer of natoms*3 floats; pass pinned memory where the runtime's own
+ * staging of pageable copies is unwanted. Every handle of a process on one GPU shares the array: a per-device lock
+ * inside the call makes calls from several threads take turns; processes have separate copies. */
 int mdx_get_forces_noalloc(mdx_system *sys, float *f);
 int mdx_get_energies(mdx_system *sys, double *e);       /* MDX_E_N doubles, last energy step */
 int mdx_get_virial(mdx_system *sys, double *vir9, double *pres9);

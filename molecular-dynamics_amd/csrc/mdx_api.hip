@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <mutex>
 
 static thread_local std::string g_create_err;
 
@@ -40,11 +41,17 @@ static int dev_upload(mdx_system *s, T **p, const std::vector<T> &h)
 static __device__ __align__(256) float scratch[3 * (size_t)MDX_NOALLOC_MAX_ATOMS];      // 12 MiB
 static float *g_scratch_ptr[MDX_MAX_DEVICES] = { nullptr };
 static hipError_t g_scratch_err[MDX_MAX_DEVICES] = { hipSuccess };
+// One lock per device (static storage: taking it allocates nothing). It guards the look-up below and, in
+// mdx_get_forces_noalloc, the section from the merge into the array to the end of the copy out of it, so that handles
+// driven from different threads of one process take turns on a GPU's array. Other processes have their own copy.
+static std::mutex g_scratch_lock[MDX_MAX_DEVICES];
 
 // With `device` current: look the device's copy of `scratch` up once.
 static void scratch_lookup(int device)
 {
-    if (device < 0 || device >= MDX_MAX_DEVICES || g_scratch_ptr[device]) return;
+    if (device < 0 || device >= MDX_MAX_DEVICES) return;
+    std::lock_guard<std::mutex> guard(g_scratch_lock[device]);
+    if (g_scratch_ptr[device]) return;
     float *p = nullptr;
     const hipError_t e = hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch));
     g_scratch_err[device] = e;
@@ -773,7 +780,7 @@ extern "C" int mdx_get_forces(mdx_system *s, float *f)
 
 // mdx_get_forces without any allocation: the merged forces are staged in the file-scope scratch array of the
 // handle's device (address looked up at mdx_create), then copied to the caller's buffer on the handle's stream.
-// All handles on one GPU share that array: calls that overlap on one GPU race.
+// All handles of a process on one GPU share that array: a per-device lock makes their calls take turns.
 extern "C" int mdx_get_forces_noalloc(mdx_system *s, float *f)
 {
     (void)hipSetDevice(s->device);
@@ -784,10 +791,15 @@ extern "C" int mdx_get_forces_noalloc(mdx_system *s, float *f)
         return MDX_ERR_OVERFLOW;
     }
     ARG_CHECK(s, s->forces_current, "mdx_get_forces_noalloc: no forces computed at the current positions");
-    float *stage = (s->device >= 0 && s->device < MDX_MAX_DEVICES) ? g_scratch_ptr[s->device] : nullptr;
+    if (s->device < 0 || s->device >= MDX_MAX_DEVICES) {
+        s->err = "mdx_get_forces_noalloc: the fixed scratch exists on devices 0 .. " + std::to_string(MDX_MAX_DEVICES - 1) + " only (use mdx_get_forces)";
+        return MDX_ERR_UNSUPPORTED;
+    }
+    std::lock_guard<std::mutex> guard(g_scratch_lock[s->device]);
+    float *stage = g_scratch_ptr[s->device];
     if (!stage) {
         s->err = std::string("mdx_get_forces_noalloc: no scratch on this device (hipGetSymbolAddress: ") +
-                 hipGetErrorString(s->device >= 0 && s->device < MDX_MAX_DEVICES ? g_scratch_err[s->device] : hipErrorInvalidDevice) + ")";
+                 hipGetErrorString(g_scratch_err[s->device]) + ")";
         return MDX_ERR_HIP;
     }
     // every one of the 3n staged values is written by the merge kernel: nothing of an earlier call survives

@@ -16,6 +16,7 @@
 #define MDX_GTAB_N 4096          // points of the tabulated Ewald correction used by the force-only nonbonded kernel
 #define MDX_LINCS_MAXK 16        // constraints per coupled component
 
+#define MDX_NREP 64              // replicas of the energy-step accumulators (one per lane of the wave that folds them)
 // Device-resident scalars: written by kernels, read by kernels, copied to the host on demand.
 struct DevState {
     DevBox box;                   // float box used by every kernel
@@ -58,16 +59,15 @@ struct DevState {
     // Replicated accumulators of the energy steps: thousands of workgroups adding doubles to one
     // address serialise in L2, so each adds to replica (block index mod MDX_NREP) and
     // k_finish_energy folds the replicas into ener / vir / ekin_tensor / npairs.
-    double ener_rep[64][MDX_E_N];
-    double vir_rep[64][9];
-    double ekt_rep[64][9];
-    unsigned long long npairs_rep[64][2];
+    double ener_rep[MDX_NREP][MDX_E_N];
+    double vir_rep[MDX_NREP][9];
+    double ekt_rep[MDX_NREP][9];
+    unsigned long long npairs_rep[MDX_NREP][2];
     // `refcoord_scaling = com`: plain average of the restraint reference positions, scaled with the box, and its value
     // before the last coupling step (the scaling kernel shifts every reference by the difference)
     double posres_com[3], posres_com_old[3];
     long long ts_min[24], ts_max[24];   // diagnostic build (-DMDX_STAMPS): first start and last end of each kernel, 100 MHz clock
 };
-#define MDX_NREP 64
 #ifdef __HIPCC__
 // Diagnostic build only: every workgroup records when it starts and ends, per kernel id, so that one step's
 // real timeline can be read without a tracing tool between the streams.

@@ -22,6 +22,7 @@
 #include <limits.h>
 #include <math.h>
 #include <vector>
+#include <atomic>
 #include <thread>
 #include <mutex>
 #include <condition_variable>
@@ -231,18 +232,24 @@ public:
         for (std::thread &t : th) t.join();
     }
 };
+// One pool per calling thread, shared by every call site (a thread_local inside the template below would be one pool
+// per instantiation, i.e. per lambda).
+static SlicePool &thread_slice_pool()
+{
+    static thread_local SlicePool pool;
+    return pool;
+}
 template <typename F>
 static void run_slices(int T, F fn)
 {
     if (T <= 1) { fn(0); return; }
-    static thread_local SlicePool pool;
     const std::function<void(int)> f = [&fn](int k) { fn(k); };
-    pool.run(T, f);
+    thread_slice_pool().run(T, f);
 }
 extern "C" {
 
 // segments of multi-threaded frames that had to be encoded again from the true state (diagnostic counter)
-static long long g_xtc_respeculated = 0;
+static std::atomic<long long> g_xtc_respeculated{0};
 static int g_xtc_warm = 2048;      // atoms a segment's thread walks through, without output, ahead of its segment
 
 // ---------------------------------------------------------------- xtc run encoder
@@ -699,7 +706,7 @@ int trj_trr_decode_frame(const unsigned char *data, long long len, long long *us
     return TRJ_OK;
 }
 
-long long trj_xtc_respeculated(void) { return g_xtc_respeculated; }
+long long trj_xtc_respeculated(void) { return g_xtc_respeculated.load(); }
 // Test hook: length of the warm-up walk (0 makes nearly every segment start from a wrong guess, which exercises the
 // path that encodes a segment again from the true state). Returns the previous value.
 int trj_xtc_set_warmup(int atoms) { const int old = g_xtc_warm; g_xtc_warm = atoms < 0 ? 0 : atoms; return old; }

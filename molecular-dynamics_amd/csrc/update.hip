@@ -557,6 +557,7 @@ __global__ void k_finish_energy(DevState *dw, int ntc, double ndf_total, int dis
     {
         constexpr int NQ = MDX_E_N + 18;
         static_assert(NQ <= 64, "one lane per folded quantity");
+        static_assert(MDX_NREP == 64, "the fold below takes one replica per lane of a 64-wide wave");
         __shared__ double fold[NQ * 65];
         __shared__ unsigned long long foldn[2 * 64];
         const int t = threadIdx.x & 63;

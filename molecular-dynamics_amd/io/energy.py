@@ -95,12 +95,13 @@ def performance_block(nsteps: int, dt_ps: float, wall_s: float) -> str:
 # The energy file of GROMACS ("enx", file version 5) as its source documents it (src/gromacs/fileio/enxio.cpp,
 # do_enxnms / do_eheader / do_enx), written the way a double-precision build writes it (a reader tells the precision
 # from the first real of a frame, -2e10, and `gmx energy` accepts either):
-#   file head   int -55555 | int version = 5 | int nre | nre x (XDR string name, XDR string unit)
+#   file head   int -55555 | int version = 5 | int nre | nre x (string name, string unit)
 #   every frame real -2e10 | int -7777777 | int version | double t | int64 step | int nsum | int64 nsteps | double dt
 #               | int nre | int 0 | int nblock = 0 | int e_size | int 0 | int 0 | nre x real e
 #               (nsum = 0: no running sums, so a term is its value only; with nsum > 0 each term would be followed by
 #               its average and sum)
-# XDR: big endian, strings as a 4-byte length and the bytes padded to a multiple of four.
+# XDR: big endian. A string goes through the file layer's string routine (gmx_fio_do_string): first an int holding
+# strlen + 1, then the XDR string itself, i.e. an unsigned length (strlen) and the bytes padded to a multiple of four.
 # No GROMACS is installed where this was written: the layout follows the description above and is read back by
 # `read_edr`; it has not been opened by `gmx energy`.
 ENX_NAMES_MAGIC, ENX_FRAME_MAGIC, ENX_VERSION, ENX_FIRST_REAL = -55555, -7777777, 5, -2e10
@@ -108,7 +109,7 @@ ENX_NAMES_MAGIC, ENX_FRAME_MAGIC, ENX_VERSION, ENX_FIRST_REAL = -55555, -7777777
 
 def _xdr_string(s: str) -> bytes:
     b = s.encode()
-    return struct.pack(">i", len(b)) + b + b"\0" * (-len(b) % 4)
+    return struct.pack(">iI", len(b) + 1, len(b)) + b + b"\0" * (-len(b) % 4)
 
 
 class EdrWriter:
@@ -151,8 +152,10 @@ def read_edr(path: str):
     names, units = [], []
     for _ in range(n):
         for dst in (names, units):
-            (ln,) = struct.unpack_from(">i", data, pos)
-            pos += 4
+            slen, ln = struct.unpack_from(">iI", data, pos)
+            if slen != ln + 1:
+                raise ValueError(f"{path}: string at byte {pos}: size field {slen} does not match length {ln}")
+            pos += 8
             dst.append(data[pos:pos + ln].decode())
             pos += ln + (-ln % 4)
     frames = []

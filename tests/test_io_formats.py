@@ -375,13 +375,13 @@ def test_log_blocks_and_edr_roundtrip(tmp_path):
     assert "Temperature" in names and units[names.index("Pressure")] == "bar"
     assert [f[0] for f in frames] == [0, 10] and frames[1][2][names.index("Potential")] == e["POT"]
     # the enx layout, byte for byte at the places its description fixes: names block -55555 / version 5 / nre, first
-    # string "Bond" as length + padded bytes, and after the 19 (name, unit) pairs a frame that starts with the
+    # string "Bond" as the file layer writes strings (int strlen + 1, then the XDR string: unsigned length and padded bytes), and after the 19 (name, unit) pairs a frame that starts with the
     # double -2e10, -7777777, version, t, step, nsum 0, nsteps, dt, nre, 0, nblock 0, e_size, 0, 0
     import struct
     raw = (tmp_path / "a.edr").read_bytes()
     assert struct.unpack_from(">iii", raw, 0) == (-55555, 5, len(energy.TERMS))
-    assert raw[12:20] == struct.pack(">i", 4) + b"Bond" and raw[20:32] == struct.pack(">i", 6) + b"kJ/mol\0\0"
-    head = 12 + sum(4 + len(n) + (-len(n) % 4) + 4 + len(u) + (-len(u) % 4) for _, n, u in energy.TERMS)
+    assert raw[12:24] == struct.pack(">iI", 5, 4) + b"Bond" and raw[24:40] == struct.pack(">iI", 7, 6) + b"kJ/mol\0\0"
+    head = 12 + sum(8 + len(n) + (-len(n) % 4) + 8 + len(u) + (-len(u) % 4) for _, n, u in energy.TERMS)
     f0 = struct.unpack_from(">diidqiqdiiiiii", raw, head)
     assert f0 == (-2e10, -7777777, 5, 0.0, 0, 0, 1, 0.0, len(energy.TERMS), 0, 0, len(energy.TERMS) * 32, 0, 0)
     frame_bytes = struct.calcsize(">diidqiqdiiiiii") + 8 * len(energy.TERMS)
