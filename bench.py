@@ -44,11 +44,11 @@ def engine_for(s, args, phase, seed, device):
         return eng.Engine(s, dt=0.002, nstlist=10, nstcalcenergy=0, tau_t=[0.1] * len(tc), nsttcouple=10, **common)
     if args.workload == "smd":  # pull_short.mdp: dt 1 fs, rc 1.2, NVT, 4 T-groups, lincs 6/2, COM pull
         common.update(tc_groups=["Protein", "MOL", "SOL", "NA"], ref_t=[300.0] * 4, lincs_order=6, lincs_iter=2)
-        e = eng.Engine(s, dt=0.001, nstlist=args.nstlist, nstcalcenergy=100, tau_t=[0.1] * 4, nsttcouple=10, **common)
+        e = eng.Engine(s, dt=0.001, nstlist=args.nstlist, nstprune=args.nstprune, nstcalcenergy=100, tau_t=[0.1] * 4, nsttcouple=10, **common)
         e.set_pull(s.groups["ActiveSite"], s.groups["MOL"], type="constant-force", k=500.0, nstout=50)
         return e
     pc = {"c-rescale": 1, "parrinello-rahman": 2, "no": 0}[args.pcoupl]
-    return eng.Engine(s, dt=0.002, nstlist=args.nstlist, nstcalcenergy=10, tau_t=[0.1] * len(tc), nsttcouple=10,
+    return eng.Engine(s, dt=0.002, nstlist=args.nstlist, nstprune=args.nstprune, nstcalcenergy=10, tau_t=[0.1] * len(tc), nsttcouple=10,
                       pcoupl=pc, tau_p=2.0, ref_p=1.0, compressibility=4.5e-5, nstpcouple=10, dispcorr=2, **common)
 
 
@@ -182,6 +182,9 @@ def main():
     ap.add_argument("--pcoupl", default="parrinello-rahman", choices=["c-rescale", "parrinello-rahman", "no"])      # production.mdp:36
     ap.add_argument("--nstlist", type=int, default=20,
                     help="pair-list lifetime; the .mdp value 10 is a lower bound that mdrun raises on GPUs")
+    ap.add_argument("--nstprune", type=int, default=0,
+                    help="dual pair list: the list of --nstlist steps is pruned to the pairs within the short-lived radius every "
+                         "this many steps (0: one list)")
     ap.add_argument("--cpu-steps", type=int, default=50, help="steps of the CPU baseline per thread count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prep-steps", type=int, default=2000)
@@ -399,6 +402,7 @@ def main():
                                   "frames_in_flight": args.encoders if nst_xtc else 0, "threads_per_frame": args.encoder_threads if nst_xtc else 0},
                        "untimed_steps_before_warmup": args.prime_steps,
                        "natoms": s.natoms, "dt_ps": dt, "rc_nm": e.rc, "rlist_nm": round(e.rlist, 4), "nstlist": args.nstlist,
+                       "nstprune": e.nstprune, "rlist_inner_nm": (round(e.rlist_inner, 4) if e.rlist_inner else None),
                        "pme_grid": list(e.grid), "parallelism": "replicas x%d" % world},
             "pair_interactions_per_s": round(n_rc / nb_avg_s, 1) if nb_avg_s > 0 else None,
             "pair_interactions_per_s_end_to_end": round(n_rc * args.steps / elapsed_max * world, 1),

@@ -116,6 +116,14 @@ int mdx_set_constraints(mdx_system *sys, int n, const int *idx, const float *len
 /* ---- run parameters (the .mdp contract) */
 /* `rcoulomb`/`rvdw` (equal), pair-list radius, Ewald beta from `ewald-rtol`, `nstlist`. */
 int mdx_set_nonbonded(mdx_system *sys, float rc, float rlist, float ewald_beta, int nstlist);
+/* Dual pair list with a rolling prune: what mdrun does with `verlet-buffer-tolerance` when the list lives long
+ * (`nstlist = 200`, /root/reference/mdp/npt_complex.mdp:29-32). The list of mdx_set_nonbonded (radius `rlist`, rebuilt
+ * every `nstlist` steps) becomes the outer list; every `nstprune` steps the engine derives from it, beside the running
+ * step, the list of the pairs of clusters that are within `rlist_inner` at that moment, and the nonbonded kernel of
+ * the following steps walks that one. `rlist_inner` has to hold the buffer of nstprune + 1 steps, `rlist` that of
+ * `nstlist` steps. nstprune = 0 switches the scheme off (one list, as set by mdx_set_nonbonded). Call after
+ * mdx_set_nonbonded; results are those of the single list up to the pairs either buffer lets slip. */
+int mdx_set_pairlist_prune(mdx_system *sys, float rlist_inner, int nstprune);
 /* `coulombtype = PME`, `pme_order = 4`, grid from `fourierspacing`. nx=0 disables the mesh. */
 int mdx_set_pme(mdx_system *sys, int nx, int ny, int nz, int order);
 /* `dt`, `nstcalcenergy`, `nstcomm`. */

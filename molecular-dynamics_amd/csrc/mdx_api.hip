@@ -66,6 +66,8 @@ extern "C" const char *mdx_last_error(const mdx_system *sys)
     return sys ? sys->err.c_str() : g_create_err.c_str();
 }
 
+static int sync_and_check(mdx_system *s);
+
 static void host_box(const double *b, DevBox *out)
 {
     for (int a = 0; a < 9; a++) out->h[a] = (float)b[a];
@@ -155,7 +157,8 @@ extern "C" void mdx_destroy(mdx_system *s)
                      s->col_count, s->col_astart, s->col_scstart, s->col_atoms, s->atom_col, s->atom_slot, s->wrapped, s->cj, s->work, s->work_order, s->sc_nwork,
                      s->exclmask, s->shift_ijk, s->shiftvec, s->bond_ij, s->bond_p, s->angle_ijk, s->angle_p, s->dih_ijkl, s->dih_p,
                      s->pair_ij, s->pair_p, s->posres_idx, s->posres_ref, s->posres_k, s->settle_idx, s->cons_ij, s->cons_len,
-                     s->comp_start, s->comp_atom_start, s->comp_atoms, s->comp_local, s->free_atoms, s->d_tc, s->pull_idx[0], s->pull_idx[1], s->gtab, s->htab, s->nut_tab, s->dd_q0, s->dd_invm0, s->dd_lj0, s->d };
+                     s->comp_start, s->comp_atom_start, s->comp_atoms, s->comp_local, s->free_atoms, s->d_tc, s->pull_idx[0], s->pull_idx[1], s->gtab, s->htab, s->nut_tab, s->dd_q0, s->dd_invm0, s->dd_lj0,
+                     s->cj_in[0], s->cj_in[1], s->work_in[0], s->work_in[1], s->d };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (s->h) (void)hipHostFree(s->h);
     if (s->ener_log) (void)hipHostFree(s->ener_log);
@@ -463,6 +466,24 @@ extern "C" int mdx_set_nonbonded(mdx_system *s, float rc, float rlist, float bet
         MDX_CHECK(s, hipMemcpy(s->nut_tab, nt.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
         s->nut_n = n; s->nut_lo = lo_bits;
     }
+    return MDX_OK;
+}
+
+extern "C" int mdx_set_pairlist_prune(mdx_system *s, float rlist_inner, int nstprune)
+{
+    (void)hipSetDevice(s->device);
+    if (nstprune <= 0) { s->nstprune = 0; s->inner_valid = false; s->nb_chunk = MDX_NB_CHUNK; return MDX_OK; }
+    ARG_CHECK(s, rlist_inner >= s->rc && rlist_inner <= s->rlist, "mdx_set_pairlist_prune: need rc <= rlist_inner <= rlist (set the outer list first)");
+    ARG_CHECK(s, !s->dd_on, "mdx_set_pairlist_prune: not available for the domains of a decomposed run");
+    int rc = sync_and_check(s); if (rc) return rc;
+    for (int k = 0; k < 2; k++) {
+        if ((rc = dev_alloc(s, &s->cj_in[k], (size_t)s->cj_cap))) return rc;
+        if ((rc = dev_alloc(s, &s->work_in[k], (size_t)s->work_cap))) return rc;
+    }
+    s->rlist_inner = rlist_inner; s->nstprune = nstprune;
+    // longer units in the outer list, so that what is left of a unit after pruning still amortises the unit's fixed costs
+    s->nb_chunk = 48;
+    s->inner_valid = false; s->steps_since_search = 1 << 30;
     return MDX_OK;
 }
 
@@ -893,6 +914,7 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
     const bool do_pc = s->pcoupl != 0 && (step % s->nstpcouple == 0);
     const bool need_vir = do_ener || do_pc;
     const bool tc_apply = s->ntc > 0 && (step % s->nsttcouple == 0);
+    bool pruned = false;
     if (phase != 2) {
         if (s->first_step && s->ntc > 0 && !(s->dd_on && !s->dd_own_tcouple)) {
             if ((rc = mdx_launch_clear(s, false, true, false))) return rc;
@@ -928,6 +950,14 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
         if (s->pull_on) {
             const bool log_now = (step % s->pull_nstout == 0);
             if ((rc = mdx_launch_pull(s, log_now, need_vir))) return rc;
+        }
+        // Rolling prune of the pair list: beside this step's nonbonded kernel (which still reads the list of the last
+        // prune, or on a search step the outer list itself) the bonded stream derives the list of the coming steps
+        // from this step's coordinates. The join below orders it ahead of the next nonbonded launch.
+        if (s->nstprune > 0 && phase == 0 && !s->dd_on && s->steps_since_search % s->nstprune == 0 &&
+            s->steps_since_search + 1 < s->nstlist) {
+            if ((rc = mdx_launch_prune(s, s->st_bond))) return rc;
+            pruned = true;
         }
         if (phase == 1) return MDX_OK;
     }
@@ -1016,6 +1046,7 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
     s->step++;
     s->steps_since_search++;
     s->forces_current = false;
+    if (pruned) { s->inner_cur ^= 1; s->inner_valid = true; }       // the list written beside this step serves from the next one
     return MDX_OK;
 }
 

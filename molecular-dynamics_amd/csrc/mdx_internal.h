@@ -186,6 +186,14 @@ struct mdx_system {
     float4 *nut_tab = nullptr;    // force table on the bits of r^2 (nonbonded.hip, k_nonbonded_f3tn): nut_n intervals from the bit pattern nut_lo
     int nut_n = 0; unsigned nut_lo = 0; bool nut_attr_set = false;
     int nstlist = 10;
+    // Dual pair list (mdx_set_pairlist_prune): the list above is built at `rlist` for `nstlist` steps; every `nstprune`
+    // steps a kernel on the bonded stream keeps the tiles of it that have a pair within `rlist_inner` right now, and the
+    // nonbonded kernel of the following steps walks that shorter list. Two inner lists: one is read while the other is written.
+    float rlist_inner = 0.0f; int nstprune = 0;
+    int nb_chunk = MDX_NB_CHUNK;       // entries per work unit the builder cuts (<= 64: one list entry per lane)
+    NbEntry *cj_in[2] = { nullptr, nullptr }; NbWork *work_in[2] = { nullptr, nullptr };
+    int inner_cur = 0;                 // the inner list the nonbonded kernel reads
+    bool inner_valid = false;          // ... exists for the current outer list
     // PME
     int K[3] = {0, 0, 0};
     float *grid = nullptr; float2 *cgrid = nullptr;
@@ -277,6 +285,7 @@ struct mdx_system {
 // kernels' host launchers (each returns MDX_OK or an error code)
 int mdx_set_stream_mode(mdx_system *s, int one_stream);
 int mdx_search(mdx_system *s);
+int mdx_launch_prune(mdx_system *s, hipStream_t st);
 int mdx_fork(mdx_system *s);
 int mdx_join(mdx_system *s);
 int mdx_launch_prepare(mdx_system *s, bool fork = false);

@@ -599,7 +599,10 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
     A.do_pairs = (terms & MDX_F_NONBONDED) ? 1 : 0;
     A.do_excl = ((terms & MDX_F_EXCL) && s->beta > 0.0f) ? 1 : 0;
     if (!A.do_pairs && !A.do_excl) return MDX_OK;
-    A.d = s->d; A.dw = s->d; A.work = s->work; A.order = s->work_order; A.cj = s->cj; A.exclmask = s->exclmask; A.xq_s = s->xq_s; A.lj_s = s->lj_s;
+    A.d = s->d; A.dw = s->d; A.work = s->work; A.order = s->work_order; A.cj = s->cj;
+    // (dual pair list: the pruned list of the current outer list, once its first pruning has run)
+    if (s->inner_valid && s->nstprune > 0) { A.work = s->work_in[s->inner_cur]; A.cj = s->cj_in[s->inner_cur]; }
+    A.exclmask = s->exclmask; A.xq_s = s->xq_s; A.lj_s = s->lj_s;
     A.shiftvec = s->shiftvec; A.f_s = s->f_s;
     A.rc2 = s->rc * s->rc; A.beta = s->beta;
     A.c_rf_shift = (float)(erfc((double)s->beta * s->rc) / s->rc);

@@ -287,6 +287,7 @@ struct ListArgs {
     int *sc_nwork;               // units in use per i-super-cluster
     unsigned char *exclmask;     // 64-byte masks, MDX_EXCL_PER_WAVE slots per (super-cluster, wave)
     float rlist;
+    int chunk;                   // list entries per work unit (<= 64)
     int dbg;                     // diagnostic ablation bits (timing experiments only)
 };
 
@@ -503,17 +504,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
         __syncthreads();
         const int nent = min(s_nent, EBUF);
         if (nent) {
-            const int nw = (nent + MDX_NB_CHUNK - 1) / MDX_NB_CHUNK;
+            const int chunk = A.chunk;
+            const int nw = (nent + chunk - 1) / chunk;
             // entries and work units go to regions owned by this super-cluster: no global counters
             const int start = sci * MDX_CJ_PER_SC + s_start, w0 = sci * MDX_WORK_PER_SC + s_w0;
             if (s_start + nent <= MDX_CJ_PER_SC && s_w0 + nw <= MDX_WORK_PER_SC) {
                 for (int k = threadIdx.x; k < nent; k += 256) A.cj[start + k] = ebuf[k];
                 for (int k = threadIdx.x; k < nw; k += 256) {
-                    NbWork w; w.sci = sci; w.cj_start = start + k * MDX_NB_CHUNK;
-                    w.cj_end = min(start + nent, w.cj_start + MDX_NB_CHUNK);
+                    NbWork w; w.sci = sci; w.cj_start = start + k * chunk;
+                    w.cj_end = min(start + nent, w.cj_start + chunk);
                     // cost = number of 8x8 tiles of the unit, kept next to the shift index for the sort
                     int cost = 0;
-                    for (int q = k * MDX_NB_CHUNK; q < min(nent, (k + 1) * MDX_NB_CHUNK); q++) cost += __popc(ebuf[q].mask & 0xFFu);
+                    for (int q = k * chunk; q < min(nent, (k + 1) * chunk); q++) cost += __popc(ebuf[q].mask & 0xFFu);
                     w.shift = s | (cost << 8);
                     A.work[w0 + k] = w;
                     atomicAdd(&s_tiles, cost);
@@ -533,6 +535,92 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
         atomicAdd(&A.d->ntiles, (unsigned long long)s_tiles);
     }
     if (lane == 0 && wslots) atomicAdd(&A.d->nexcl, wslots);
+}
+
+// Rolling prune of the pair list (the dual-list scheme of `verlet-buffer-tolerance` with a long `nstlist`,
+// /root/reference/mdp/npt_complex.mdp:29-32): the list above is built with the buffer of its whole lifetime; this
+// kernel derives from it, from the coordinates of the current step, the list of the next few steps: a tile stays when
+// one of its 64 atom pairs is within `rl2` now. One wave per work unit, lane (ti, tj) = (i-atom, j-atom) as in the
+// nonbonded kernel; lane e keeps entry e and its new i-cluster mask, and the surviving entries are written compacted
+// to the same place of the inner list (units keep their index, so the cost order of the outer list serves both).
+struct PruneArgs {
+    const DevState *d;
+    const NbWork *work; const int *order; const NbEntry *cj;
+    const float4 *xq_s; const float4 *shiftvec;
+    NbWork *work_out; NbEntry *cj_out;
+    float rl2;
+};
+
+__global__ __launch_bounds__(256) void k_prune_list(PruneArgs A)
+{
+    MDX_STAMP(A.d, 18);
+    const int lane = threadIdx.x & 63, ti = lane & 7, tj = lane >> 3;
+    const int nwork = A.d->nwork;
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    for (int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); k < nwork; k += nwaves) {
+        const int u = A.order[k];
+        const NbWork w = A.work[u];
+        const int sci = __builtin_amdgcn_readfirstlane(w.sci);
+        const int e0 = __builtin_amdgcn_readfirstlane(w.cj_start);
+        const int count = __builtin_amdgcn_readfirstlane(w.cj_end) - e0;
+        const float4 S = A.shiftvec[__builtin_amdgcn_readfirstlane(w.shift) & 0xFF];
+        NbEntry myent; myent.cj = 0; myent.mask = 0;
+        if (lane < count) myent = A.cj[e0 + lane];
+        float xi[8], yi[8], zi[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const float4 p = A.xq_s[(sci * 8 + c) * 8 + ti];
+            xi[c] = p.x - S.x; yi[c] = p.y - S.y; zi[c] = p.z - S.z;
+        }
+        unsigned newmask = 0;           // of this lane's entry
+        // four entries at a time: their j-atoms are requested together (one memory round trip per four entries)
+        for (int eb = 0; eb < count; eb += 4) {
+            float4 pj[4]; unsigned im[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int e = min(eb + q, count - 1);
+                const int cj = __builtin_amdgcn_readlane(myent.cj, e);
+                im[q] = eb + q < count ? ((unsigned)__builtin_amdgcn_readlane((int)myent.mask, e) & 0xFFu) : 0u;
+                pj[q] = A.xq_s[cj * 8 + tj];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                unsigned keep = 0;
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    if (!(im[q] & (1u << c))) continue;          // wave-uniform
+                    const float dx = xi[c] - pj[q].x, dy = yi[c] - pj[q].y, dz = zi[c] - pj[q].z;
+                    const float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                    if (__builtin_amdgcn_ballot_w64(r2 < A.rl2) != 0ull) keep |= 1u << c;
+                }
+                if (lane == eb + q) newmask = keep;
+            }
+        }
+        const unsigned long long alive = __builtin_amdgcn_ballot_w64(newmask != 0u);
+        const int pos = __popcll(alive & ((1ull << lane) - 1ull));
+        if (newmask != 0u) {
+            NbEntry o; o.cj = myent.cj; o.mask = (myent.mask & ~0xFFu) | newmask;
+            A.cj_out[e0 + pos] = o;
+        }
+        if (lane == 0) {
+            NbWork o = w; o.cj_end = e0 + __popcll(alive);
+            A.work_out[u] = o;
+        }
+    }
+}
+
+int mdx_launch_prune(mdx_system *s, hipStream_t st)
+{
+    if (s->nstprune <= 0 || !s->cj_in[0]) return MDX_OK;
+    const int dst = s->inner_cur ^ 1;
+    PruneArgs A;
+    A.d = s->d; A.work = s->work; A.order = s->work_order; A.cj = s->cj; A.xq_s = s->xq_s; A.shiftvec = s->shiftvec;
+    A.work_out = s->work_in[dst]; A.cj_out = s->cj_in[dst];
+    A.rl2 = s->rlist_inner * s->rlist_inner;
+    // a few waves per SIMD beside the nonbonded kernel's: the kernel is a chain of dependent loads and short tests
+    hipLaunchKernelGGL(k_prune_list, dim3(1024), dim3(256), 0, st, A);
+    MDX_CHECK(s, hipGetLastError());
+    return MDX_OK;
 }
 
 // Order the work units by descending tile count (counting sort on the cost stored next to the
@@ -686,10 +774,12 @@ int mdx_search(mdx_system *s)
     A.shiftvec = s->shiftvec; A.nshift = s->nshift; A.central = s->central_shift; A.excl_start = s->excl_start;
     A.excl_list = s->excl_list; A.cj = s->cj; A.work = s->work; A.sc_nwork = s->sc_nwork;
     A.exclmask = s->exclmask; A.rlist = s->rlist; A.dbg = s->dbg;
+    A.chunk = std::min(64, std::max(8, s->nb_chunk));
     const int nblk = s->npad / 64;
     hipLaunchKernelGGL(k_build_list, dim3(nblk), dim3(256), 0, s->stream, A);
     hipLaunchKernelGGL(k_sort_work, dim3(32), dim3(1024), 0, s->stream, s->d, s->work, s->sc_nwork, s->work_order);
     MDX_CHECK(s, hipGetLastError());
     s->steps_since_search = 0;
+    s->inner_valid = false;         // the nonbonded kernel walks the new list itself until its first pruning has run
     return MDX_OK;
 }

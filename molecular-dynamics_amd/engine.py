@@ -28,7 +28,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmdx.so")
 SYMBOLS = [
     "mdx_version", "mdx_last_error", "mdx_create", "mdx_destroy", "mdx_set_atoms", "mdx_set_exclusions",
     "mdx_set_bonds", "mdx_set_angles", "mdx_set_dihedrals", "mdx_set_pairs14", "mdx_set_posres", "mdx_get_posres_ref", "mdx_set_settles",
-    "mdx_set_constraints", "mdx_set_nonbonded", "mdx_set_pme", "mdx_set_integrator", "mdx_set_tcoupl",
+    "mdx_set_constraints", "mdx_set_nonbonded", "mdx_set_pairlist_prune", "mdx_set_pme", "mdx_set_integrator", "mdx_set_tcoupl",
     "mdx_set_pcoupl", "mdx_set_dispcorr", "mdx_set_pull", "mdx_set_state", "mdx_set_state_device", "mdx_get_state",
     "mdx_get_step", "mdx_get_run_state", "mdx_set_run_state", "mdx_compute_forces", "mdx_get_forces", "mdx_get_forces_noalloc", "mdx_get_energies", "mdx_get_virial", "mdx_step",
     "mdx_synchronize", "mdx_get_list_stats", "mdx_pop_energy_frames", "mdx_pop_pull_records",
@@ -98,6 +98,7 @@ def load_library(path: str | None = None):
     L.mdx_set_settles.argtypes = [vp, c_int, ip, c_f, c_f]
     L.mdx_set_constraints.argtypes = [vp, c_int, ip, fp, c_int, c_int]
     L.mdx_set_nonbonded.argtypes = [vp, c_f, c_f, c_f, c_int]
+    L.mdx_set_pairlist_prune.argtypes = [vp, c_f, c_int]
     L.mdx_set_pme.argtypes = [vp, c_int, c_int, c_int, c_int]
     L.mdx_set_integrator.argtypes = [vp, c_f, c_int, c_int]
     L.mdx_set_tcoupl.argtypes = [vp, c_int, dp, dp, dp, c_int, ctypes.c_ulonglong]
@@ -300,7 +301,7 @@ class Engine:
                  tc_groups=None, ref_t=None, tau_t=None, nsttcouple=10, seed=1,
                  pcoupl=0, tau_p=2.0, ref_p=1.0, compressibility=4.5e-5, nstpcouple=10,
                  dispcorr=0, lincs_order=4, lincs_iter=1, refcoord_scaling=0, use_posres=False, beta=None,
-                 verlet_buffer_tolerance=0.005):
+                 verlet_buffer_tolerance=0.005, nstprune=0, rlist_inner=None):
         self.lib = load_library()
         self.sys = sysm
         n = sysm.natoms
@@ -317,6 +318,15 @@ class Engine:
             rlist = verlet_buffer_rlist(sysm, rc, self.beta if pme else 0.0, nstlist, dt, max(t_ref, 1.0),
                                         float(verlet_buffer_tolerance))
         self.rlist = float(rlist)
+        # dual pair list: the outer list lives `nstlist` steps, the pruned inner list serves nstprune + 1 steps at most
+        self.nstprune = int(nstprune) if nstprune and int(nstprune) < int(nstlist) else 0
+        self.rlist_inner = None
+        if self.nstprune > 0:
+            if rlist_inner is None:
+                t_ref = max([float(x) for x in ref_t]) if ref_t is not None and len(ref_t) else 300.0
+                rlist_inner = verlet_buffer_rlist(sysm, rc, self.beta if pme else 0.0, self.nstprune + 1, dt, max(t_ref, 1.0),
+                                                  float(verlet_buffer_tolerance))
+            self.rlist_inner = float(min(max(float(rlist_inner), self.rc), self.rlist))
         # T-coupling groups
         tcg = np.zeros(n, dtype=np.int32)
         ndf = []
@@ -340,6 +350,8 @@ class Engine:
         self.ndf_total = float(3.0 * n - nc_atom.sum() - (3.0 if nstcomm > 0 else 0.0))
         self._call("mdx_set_nonbonded", ctypes.c_float(self.rc), ctypes.c_float(self.rlist), ctypes.c_float(self.beta if pme else 0.0),
                    int(nstlist))
+        if self.nstprune > 0:
+            self._call("mdx_set_pairlist_prune", ctypes.c_float(self.rlist_inner), self.nstprune)
         m, q, sg, ep = _f32(sysm.mass), _f32(sysm.charge), _f32(sysm.sigma), _f32(sysm.eps)
         mol = _i32(sysm.molid)
         self._call("mdx_set_atoms", _p(m, ctypes.c_float), _p(q, ctypes.c_float), _p(sg, ctypes.c_float), _p(ep, ctypes.c_float),
