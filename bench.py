@@ -180,11 +180,13 @@ def main():
     ap.add_argument("--workload", default="production", choices=["production", "smd", "dd"],
                     help="dd: the tiled ~1.1 M-atom water box decomposed over the N GPUs (strong scaling); not the default")
     ap.add_argument("--pcoupl", default="parrinello-rahman", choices=["c-rescale", "parrinello-rahman", "no"])      # production.mdp:36
-    ap.add_argument("--nstlist", type=int, default=20,
-                    help="pair-list lifetime; the .mdp value 10 is a lower bound that mdrun raises on GPUs")
-    ap.add_argument("--nstprune", type=int, default=0,
+    ap.add_argument("--nstlist", type=int, default=0,
+                    help="pair-list lifetime; the .mdp value 10 is a lower bound that mdrun raises on GPUs. Default: 100 with the "
+                         "list pruned every 10 steps (dual list), 20 for the decomposed workload")
+    ap.add_argument("--nstprune", type=int, default=-1,
                     help="dual pair list: the list of --nstlist steps is pruned to the pairs within the short-lived radius every "
-                         "this many steps (0: one list)")
+                         "this many steps (0: one list; default 10 with the default --nstlist)")
+    ap.add_argument("--nb-chunk", type=int, default=0, help="diagnostic: list entries per nonbonded work unit (0: the library's 32)")
     ap.add_argument("--cpu-steps", type=int, default=50, help="steps of the CPU baseline per thread count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prep-steps", type=int, default=2000)
@@ -201,6 +203,11 @@ def main():
                          "back to its sustained clocks after the host-side set-up of the run: with 40 of them a 20-step window "
                          "still saw the nonbonded kernel at 0.123 ms per launch, with 400 at the 0.113 ms of a long run")
     args = ap.parse_args()
+    if args.nstlist <= 0:
+        args.nstlist = 20 if args.workload == "dd" else 100
+        if args.nstprune < 0:
+            args.nstprune = 0 if args.workload == "dd" else 10
+    args.nstprune = max(args.nstprune, 0)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)
@@ -250,6 +257,8 @@ def main():
     e = engine_for(s, args, "relax", seed, local); e.step(args.prep_steps); s1 = carry(s, e); e.close()
     e = engine_for(s1, args, "equil", seed, local); e.step(args.prep_steps); s2 = carry(s1, e); e.close()
     e = engine_for(s2, args, "run", seed, local)
+    if args.nb_chunk:
+        e.debug_set(14, args.nb_chunk)
     if os.environ.get("MDX_NB_VARIANT"):      # diagnostic A/B of nonbonded launch shapes
         e.debug_set(1, int(os.environ["MDX_NB_VARIANT"]))
     for kv in filter(None, os.environ.get("MDX_DEBUG", "").split(",")):     # diagnostic switches "key=value,..."
@@ -426,13 +435,15 @@ def main():
             # 4 threads as the pipeline runs gmx mdrun (-ntomp 4, /root/reference/Snakefile:232-233), and the cores of this job
             ncores = min(16, os.cpu_count() or 4)
             runs = []
+            cpu_rlist = eng.verlet_buffer_rlist(s3, e.rc, e.beta, 20, dt, 300.0, 0.005)
             for threads in sorted({4, ncores}):
-                v, wall, timers = cpu_baseline(s3, e.rc, e.rlist, e.grid, dt, args.cpu_steps, threads)
+                # (the CPU path keeps one list for 20 steps: it gets the radius of a 20-step list, not the GPU's outer radius)
+                v, wall, timers = cpu_baseline(s3, e.rc, cpu_rlist, e.grid, dt, args.cpu_steps, threads)
                 runs.append({"threads": threads, "ns_per_day": round(v, 4), "ms_per_step": round(wall / args.cpu_steps * 1e3, 2),
                              "seconds": round(wall, 1), "phases_s": timers})
             gmx = find_gromacs()
             out["cpu_baseline"] = {"value": runs[0]["ns_per_day"], "unit": "ns/day", "cores": runs[0]["threads"], "kind": "port",
-                                   "sample": "%d leap-frog steps of the same %d-atom system (same rc, pair-list radius and PME grid) on "
+                                   "sample": "%d leap-frog steps of the same %d-atom system (same rc and PME grid, pair-list radius of its 20-step list) on "
                                              "the host: own CPU restatement, not GROMACS (single precision, OpenMP C, Verlet list "
                                              "reused for 20 steps, pocketfft transforms; oracle/cpu_md.*)" % (args.cpu_steps, s.natoms),
                                    "runs": runs, "gmx": gmx or "unavailable",

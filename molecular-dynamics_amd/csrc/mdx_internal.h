@@ -55,6 +55,8 @@ struct DevState {
     unsigned long long ntiles;    // 8x8 tiles in the pair list (statistics)
     int cost_hist[258];           // work units per tile count (last bin: 256 and more), filled by the list builder
     int cost_cursor[258];         // positions handed out per tile count by the sort of the units
+    int cost_hist_in[258], cost_cursor_in[258];   // the same for the units of a pruned list (cleared ahead of every pruning)
+    int nwork_in[2];              // units with a tile left in either pruned list
     int nb_head[8 * 32];          // dequeue counters of the nonbonded kernel's eight unit queues, one cache line each (cleared every step)
     // Replicated accumulators of the energy steps: thousands of workgroups adding doubles to one
     // address serialise in L2, so each adds to replica (block index mod MDX_NREP) and
@@ -191,7 +193,7 @@ struct mdx_system {
     // nonbonded kernel of the following steps walks that shorter list. Two inner lists: one is read while the other is written.
     float rlist_inner = 0.0f; int nstprune = 0;
     int nb_chunk = MDX_NB_CHUNK;       // entries per work unit the builder cuts (<= 64: one list entry per lane)
-    NbEntry *cj_in[2] = { nullptr, nullptr }; NbWork *work_in[2] = { nullptr, nullptr };
+    NbEntry *cj_in[2] = { nullptr, nullptr }; NbWork *work_in[2] = { nullptr, nullptr }; int *order_in[2] = { nullptr, nullptr };
     int inner_cur = 0;                 // the inner list the nonbonded kernel reads
     bool inner_valid = false;          // ... exists for the current outer list
     // PME

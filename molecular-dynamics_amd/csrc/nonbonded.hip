@@ -20,6 +20,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));      // two floats in an 
 
 struct NbArgs {
     const DevState *d;
+    const int *nwork;            // number of work units (device memory: the list builder or the pruning kernel counts them)
     const NbWork *work;
     const int *order;            // work units by descending cost
     const NbEntry *cj;
@@ -113,7 +114,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
     if (TIMED) { t_start = clock64(); w_start = wall_clock64(); }
     const int lane = threadIdx.x & 63;
     const int ti = lane & 7, tj = lane >> 3;
-    const int nwork = A.d->nwork;
+    const int nwork = *A.nwork;
     const int wpb = blockDim.x >> 6;          // waves per workgroup
     const int nwaves = gridDim.x * wpb;
     float elj = 0.0f, ecoul = 0.0f, eexcl = 0.0f;
@@ -601,7 +602,11 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
     if (!A.do_pairs && !A.do_excl) return MDX_OK;
     A.d = s->d; A.dw = s->d; A.work = s->work; A.order = s->work_order; A.cj = s->cj;
     // (dual pair list: the pruned list of the current outer list, once its first pruning has run)
-    if (s->inner_valid && s->nstprune > 0) { A.work = s->work_in[s->inner_cur]; A.cj = s->cj_in[s->inner_cur]; }
+    A.nwork = &s->d->nwork;
+    if (s->inner_valid && s->nstprune > 0) {
+        A.work = s->work_in[s->inner_cur]; A.cj = s->cj_in[s->inner_cur]; A.order = s->order_in[s->inner_cur];
+        A.nwork = &s->d->nwork_in[s->inner_cur];
+    }
     A.exclmask = s->exclmask; A.xq_s = s->xq_s; A.lj_s = s->lj_s;
     A.shiftvec = s->shiftvec; A.f_s = s->f_s;
     A.rc2 = s->rc * s->rc; A.beta = s->beta;
@@ -741,6 +746,7 @@ extern "C" int mdx_debug_set(mdx_system *s, int key, int value)
     if (key == 11) { s->count_pairs_steps = s->count_pairs = value != 0; return MDX_OK; }     // energy steps of mdx_step count the pairs inside the cutoff
     if (key == 13) { s->tc_on_side = value != 0; return MDX_OK; }       // thermostat kernels of plain steps on the bonded stream
     if (key == 12) { s->fused_update = value != 0; return MDX_OK; }     // leap-frog + constraints (+ next sorted coordinates) in one launch
+    if (key == 14) { s->nb_chunk = value; s->steps_since_search = 1 << 30; return MDX_OK; }   // list entries per work unit (the next search applies it)
     if (key == 10) {      // streams per handle: 1 (every kernel in one stream's order) or 3
         if (value != 1 && value != 3) { s->err = "mdx_debug_set: key 10 takes 1 or 3"; return MDX_ERR_ARG; }
         return mdx_set_stream_mode(s, value == 1);

@@ -543,11 +543,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
 // one of its 64 atom pairs is within `rl2` now. One wave per work unit, lane (ti, tj) = (i-atom, j-atom) as in the
 // nonbonded kernel; lane e keeps entry e and its new i-cluster mask, and the surviving entries are written compacted
 // to the same place of the inner list (units keep their index, so the cost order of the outer list serves both).
+__global__ void k_sort_work(DevState *__restrict__ d, const NbWork *__restrict__ work, const int *__restrict__ sc_nwork,
+                            int *__restrict__ order, int which);
+
 struct PruneArgs {
     const DevState *d;
     const NbWork *work; const int *order; const NbEntry *cj;
     const float4 *xq_s; const float4 *shiftvec;
     NbWork *work_out; NbEntry *cj_out;
+    DevState *dw;
     float rl2;
 };
 
@@ -573,18 +577,19 @@ __global__ __launch_bounds__(256) void k_prune_list(PruneArgs A)
             xi[c] = p.x - S.x; yi[c] = p.y - S.y; zi[c] = p.z - S.z;
         }
         unsigned newmask = 0;           // of this lane's entry
-        // four entries at a time: their j-atoms are requested together (one memory round trip per four entries)
-        for (int eb = 0; eb < count; eb += 4) {
-            float4 pj[4]; unsigned im[4];
+        // eight entries at a time: their j-atoms are requested together (one memory round trip per eight entries)
+        constexpr int NE = 8;
+        for (int eb = 0; eb < count; eb += NE) {
+            float4 pj[NE]; unsigned im[NE];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < NE; q++) {
                 const int e = min(eb + q, count - 1);
                 const int cj = __builtin_amdgcn_readlane(myent.cj, e);
                 im[q] = eb + q < count ? ((unsigned)__builtin_amdgcn_readlane((int)myent.mask, e) & 0xFFu) : 0u;
                 pj[q] = A.xq_s[cj * 8 + tj];
             }
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < NE; q++) {
                 unsigned keep = 0;
 #pragma unroll
                 for (int c = 0; c < 8; c++) {
@@ -602,9 +607,14 @@ __global__ __launch_bounds__(256) void k_prune_list(PruneArgs A)
             NbEntry o; o.cj = myent.cj; o.mask = (myent.mask & ~0xFFu) | newmask;
             A.cj_out[e0 + pos] = o;
         }
+        // the unit's cost (tiles left) beside the shift index, and the histogram the sort of the units starts from
+        int cost = __popc(newmask);
+        for (int o = 32; o; o >>= 1) cost += __shfl_xor(cost, o, 64);
         if (lane == 0) {
             NbWork o = w; o.cj_end = e0 + __popcll(alive);
+            o.shift = (w.shift & 0xFF) | (cost << 8);
             A.work_out[u] = o;
+            atomicAdd(&A.dw->cost_hist_in[min(256, cost)], 1);
         }
     }
 }
@@ -615,10 +625,14 @@ int mdx_launch_prune(mdx_system *s, hipStream_t st)
     const int dst = s->inner_cur ^ 1;
     PruneArgs A;
     A.d = s->d; A.work = s->work; A.order = s->work_order; A.cj = s->cj; A.xq_s = s->xq_s; A.shiftvec = s->shiftvec;
-    A.work_out = s->work_in[dst]; A.cj_out = s->cj_in[dst];
+    A.work_out = s->work_in[dst]; A.cj_out = s->cj_in[dst]; A.dw = s->d;
     A.rl2 = s->rlist_inner * s->rlist_inner;
+    MDX_CHECK(s, hipMemsetAsync((char *)s->d + offsetof(DevState, cost_hist_in), 0, sizeof(int) * 2 * 258, st));
     // a few waves per SIMD beside the nonbonded kernel's: the kernel is a chain of dependent loads and short tests
     hipLaunchKernelGGL(k_prune_list, dim3(1024), dim3(256), 0, st, A);
+    // units in the order of what pruning left of them; units left empty fall behind the count the nonbonded kernel reads
+    hipLaunchKernelGGL(k_sort_work, dim3(32), dim3(1024), 0, st, s->d, (const NbWork *)s->work_in[dst], (const int *)s->sc_nwork,
+                       s->order_in[dst], 1 + dst);
     MDX_CHECK(s, hipGetLastError());
     return MDX_OK;
 }
@@ -630,19 +644,24 @@ int mdx_launch_prune(mdx_system *s, hipStream_t st)
 // derives the first position of each cost from that histogram, counts its own slice of the sparse
 // unit array (a fixed region per i-super-cluster, sc_nwork[] of it in use), reserves a range per
 // cost with one returning atomic and scatters within the range through LDS.
+// `which` 0: the list the builder has just written; 1, 2: the first or second pruned list (own histogram, own unit
+// count, which leaves out the units that pruning has emptied: cost 0 sorts last).
 __global__ __launch_bounds__(1024) void k_sort_work(DevState *__restrict__ d, const NbWork *__restrict__ work,
-                                                    const int *__restrict__ sc_nwork, int *__restrict__ order)
+                                                    const int *__restrict__ sc_nwork, int *__restrict__ order, int which)
 {
     __shared__ int first[257], mine[257];
     const int n = d->nsc * MDX_WORK_PER_SC;
     const int per = (n + gridDim.x - 1) / gridDim.x;
     const int k0 = blockIdx.x * per, k1 = min(n, k0 + per);
-    for (int c = threadIdx.x; c < 257; c += blockDim.x) { first[c] = d->cost_hist[c]; mine[c] = 0; }
+    const int *hist = which ? d->cost_hist_in : d->cost_hist;
+    int *cursor = which ? d->cost_cursor_in : d->cost_cursor;
+    for (int c = threadIdx.x; c < 257; c += blockDim.x) { first[c] = hist[c]; mine[c] = 0; }
     __syncthreads();
     if (threadIdx.x == 0) {
         int run = 0;
+        const int empty = first[0];
         for (int c = 256; c >= 0; c--) { const int h = first[c]; first[c] = run; run += h; }
-        if (blockIdx.x == 0) d->nwork = run;
+        if (blockIdx.x == 0) { if (which) d->nwork_in[which - 1] = run - empty; else d->nwork = run; }
     }
     __syncthreads();
     for (int k = k0 + threadIdx.x; k < k1; k += blockDim.x)
@@ -650,7 +669,7 @@ __global__ __launch_bounds__(1024) void k_sort_work(DevState *__restrict__ d, co
     __syncthreads();
     for (int c = threadIdx.x; c < 257; c += blockDim.x) {
         const int m = mine[c];
-        mine[c] = m ? first[c] + atomicAdd(&d->cost_cursor[c], m) : 0;
+        mine[c] = m ? first[c] + atomicAdd(&cursor[c], m) : 0;
     }
     __syncthreads();
     for (int k = k0 + threadIdx.x; k < k1; k += blockDim.x)
@@ -777,7 +796,7 @@ int mdx_search(mdx_system *s)
     A.chunk = std::min(64, std::max(8, s->nb_chunk));
     const int nblk = s->npad / 64;
     hipLaunchKernelGGL(k_build_list, dim3(nblk), dim3(256), 0, s->stream, A);
-    hipLaunchKernelGGL(k_sort_work, dim3(32), dim3(1024), 0, s->stream, s->d, s->work, s->sc_nwork, s->work_order);
+    hipLaunchKernelGGL(k_sort_work, dim3(32), dim3(1024), 0, s->stream, s->d, (const NbWork *)s->work, (const int *)s->sc_nwork, s->work_order, 0);
     MDX_CHECK(s, hipGetLastError());
     s->steps_since_search = 0;
     s->inner_valid = false;         // the nonbonded kernel walks the new list itself until its first pruning has run

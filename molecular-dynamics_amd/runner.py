@@ -491,27 +491,34 @@ def mdrun(argv, out=sys.stdout, err=sys.stderr) -> int:
     if integrator != "md":
         tcoupl, pcoupl = "no", 0
     tc_groups = m.words("tc_grps") if tcoupl != "no" else None
-    # like mdrun on a GPU, dynamics treats the file's nstlist as a lower bound: the list lifetime is
-    # raised to 20 steps and the pair-list radius follows from the buffer estimate (`-nstlist` overrides)
-    nstlist = max(1, min(m.i("nstlist"), 20))
+    # Like mdrun on a GPU, dynamics treats the file's nstlist as a lower bound (`-nstlist` overrides): the outer pair list
+    # lives max(nstlist, 100) steps at the radius the buffer estimate gives for that time, and every 10 steps the engine
+    # prunes it to the pairs within the radius of an 11-step list (the dual list of `verlet-buffer-tolerance`,
+    # /root/reference/mdp/npt_complex.mdp:29-32). A cell too small for the outer radius gets one list of 20 steps.
+    plans = [(max(1, min(m.i("nstlist"), 20)), 0)]
     if integrator == "md":
-        nstlist = int(a.nstlist) if a.nstlist else 20
-    try:
-        eng = Engine(
-            sysm, rc=rc_, nstlist=nstlist, ewald_rtol=m.f("ewald_rtol"), pme=True, fourierspacing=m.f("fourierspacing"),
-            dt=dt, nstcalcenergy=nstcalc, nstcomm=(m.i("nstcomm") if m.s("comm_mode").lower() != "none" else 0),
-            device=device, tc_groups=tc_groups, ref_t=m.floats("ref_t") or None, tau_t=m.floats("tau_t") or None,
-            nsttcouple=nsttc, seed=_seed(m.i("ld_seed")), pcoupl=pcoupl, tau_p=m.f("tau_p"),
-            ref_p=(m.floats("ref_p") or [1.0])[0], compressibility=(m.floats("compressibility") or [4.5e-5])[0],
-            nstpcouple=nstpc, dispcorr={"no": 0, "ener": 1, "enerpres": 2}[m.s("dispcorr").lower()],
-            lincs_order=m.i("lincs_order"), lincs_iter=m.i("lincs_iter"),
-            refcoord_scaling={"no": 0, "all": 1, "com": 2}[m.s("refcoord_scaling").lower()],
-            use_posres=bool(meta.get("use_posres")),
-            rlist=(max(m.f("rlist"), rc_) if m.f("verlet_buffer_tolerance") <= 0 else None),
-            verlet_buffer_tolerance=m.f("verlet_buffer_tolerance"))
-    except (MdxError, OSError) as e:
-        err.write(f"\nProgram:     gmx mdrun ({PROGRAM})\n\nFatal error:\n{e}\n")
-        return 1
+        plans = [(int(a.nstlist), 10 if int(a.nstlist) >= 40 else 0)] if a.nstlist else [(max(m.i("nstlist"), 100), 10), (20, 0)]
+    eng = None
+    for k, (nstlist, nstprune) in enumerate(plans):
+        try:
+            eng = Engine(
+                sysm, rc=rc_, nstlist=nstlist, nstprune=nstprune, ewald_rtol=m.f("ewald_rtol"), pme=True, fourierspacing=m.f("fourierspacing"),
+                dt=dt, nstcalcenergy=nstcalc, nstcomm=(m.i("nstcomm") if m.s("comm_mode").lower() != "none" else 0),
+                device=device, tc_groups=tc_groups, ref_t=m.floats("ref_t") or None, tau_t=m.floats("tau_t") or None,
+                nsttcouple=nsttc, seed=_seed(m.i("ld_seed")), pcoupl=pcoupl, tau_p=m.f("tau_p"),
+                ref_p=(m.floats("ref_p") or [1.0])[0], compressibility=(m.floats("compressibility") or [4.5e-5])[0],
+                nstpcouple=nstpc, dispcorr={"no": 0, "ener": 1, "enerpres": 2}[m.s("dispcorr").lower()],
+                lincs_order=m.i("lincs_order"), lincs_iter=m.i("lincs_iter"),
+                refcoord_scaling={"no": 0, "all": 1, "com": 2}[m.s("refcoord_scaling").lower()],
+                use_posres=bool(meta.get("use_posres")),
+                rlist=(max(m.f("rlist"), rc_) if m.f("verlet_buffer_tolerance") <= 0 else None),
+                verlet_buffer_tolerance=m.f("verlet_buffer_tolerance"))
+            break
+        except (MdxError, OSError) as e:
+            if k + 1 < len(plans) and "shorter than twice" in str(e):
+                continue
+            err.write(f"\nProgram:     gmx mdrun ({PROGRAM})\n\nFatal error:\n{e}\n")
+            return 1
     total_mass = float(np.sum(sysm.mass))
 
     # ---- log header
@@ -523,7 +530,8 @@ def mdrun(argv, out=sys.stdout, err=sys.stderr) -> int:
                 f"Command line: gmx mdrun {' '.join(argv)}", f"Run input: {src}", f"System: {sysm.title}",
                 f"Atoms: {sysm.natoms}   rigid waters: {len(sysm.settles)}   constraints: {len(sysm.constraints)}",
                 f"PME grid: {eng.grid}   rc: {rc_}   pair-list radius: {eng.rlist:.3f}   nstlist: {nstlist}   "
-                f"Ewald beta: {eng.beta:.5f}",
+                + (f"pruned every {eng.nstprune} steps to radius {eng.rlist_inner:.3f}   " if eng.nstprune else "")
+                + f"Ewald beta: {eng.beta:.5f}",
                 f"integrator: {integrator}   dt: {dt}   nsteps: {nsteps}   nstcalcenergy: {nstcalc}",
                 "Input Parameters:"] + ["   %-28s = %s" % (k.replace("_", "-"), v) for k, v in sorted(m.items())])
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""NVE energy drift of the S2 pseudo-complex against the pair-list radius (nstlist 20, dt 2 fs): checks that the
-radius from the verlet-buffer-tolerance estimate keeps the measured drift under the tolerance (0.005 kJ/mol/ps per atom)."""
+"""NVE energy drift of the S2 pseudo-complex against the pair-list radius (nstlist 20, dt 2 fs) and on the dual pair list
+(outer list 100 steps, pruned every 10): checks that the radii from the verlet-buffer-tolerance estimate keep the
+measured drift under the tolerance (0.005 kJ/mol/ps per atom)."""
 import sys, os, copy
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, mdx
@@ -17,13 +18,13 @@ x, v, box = e.get_state(); e.close()
 s2 = copy.copy(s); s2.x = x.astype(np.float64); s2.v = v.astype(np.float64); s2.box = box.astype(np.float64)
 nsteps = int(os.environ.get("DRIFT_STEPS", "10000"))
 auto = None
-for rl in (None, 1.02, 1.05, 1.127, 1.2):
-    e = eng.Engine(s2, rc=1.0, rlist=rl, dt=0.002, nstlist=20, nstcalcenergy=10, nstcomm=100)
+for rl, nstlist, nstprune in ((None, 20, 0), (None, 100, 10), (None, 120, 12), (1.02, 20, 0), (1.05, 20, 0), (1.127, 20, 0), (1.2, 20, 0)):
+    e = eng.Engine(s2, rc=1.0, rlist=rl, dt=0.002, nstlist=nstlist, nstprune=nstprune, nstcalcenergy=10, nstcomm=100)
     if rl is None: auto = e.rlist
     e.step(nsteps)
     fr = e.pop_energy_frames()
     t = fr[:, 1]; etot = fr[:, 2 + eng.E["POT"]] + fr[:, 2 + eng.E["KIN"]]
     slope = np.polyfit(t, etot, 1)[0] / s.natoms
-    print("rlist %.3f%s: drift %+.5f kJ/mol/ps per atom   (E_tot %.1f -> %.1f, T %.1f K)" % (
-        e.rlist, " (estimate)" if rl is None else "", slope, etot[0], etot[-1], fr[-1, 2 + eng.E["TEMP"]] if "TEMP" in eng.E else -1), flush=True)
+    print("nstlist %3d nstprune %2d rlist %.3f inner %s%s: drift %+.5f kJ/mol/ps per atom   (E_tot %.1f -> %.1f, T %.1f K)" % (
+        nstlist, nstprune, e.rlist, e.rlist_inner, " (estimate)" if rl is None else "", slope, etot[0], etot[-1], fr[-1, 2 + eng.E["TEMP"]] if "TEMP" in eng.E else -1), flush=True)
     e.close()
