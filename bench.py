@@ -12,6 +12,7 @@ A "step" is one MD step. Metric: ns/day = dt * steps * 86400 / wall / 1000 summe
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -160,6 +161,88 @@ def launch_ranks(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+# production.mdp of the pipeline (/root/reference/mdp/production.mdp:3-46), key by key, with `nsteps` of the timed run
+PRODUCTION_MDP = [
+    ("integrator", "md"), ("nsteps", None), ("dt", "0.002"), ("nstxout", "10000"), ("nstvout", "0"), ("nstfout", "0"),
+    ("nstenergy", "10"), ("nstlog", "10"), ("nstxout-compressed", "10"), ("compressed-x-grps", "System"),
+    ("continuation", "yes"), ("constraint_algorithm", "lincs"), ("constraints", "h-bonds"), ("lincs_iter", "1"), ("lincs_order", "4"),
+    ("cutoff-scheme", "Verlet"), ("ns_type", "grid"), ("nstlist", "10"), ("rcoulomb", "1.0"), ("rvdw", "1.0"),
+    ("coulombtype", "PME"), ("pme_order", "4"), ("fourierspacing", "0.16"),
+    ("tcoupl", "V-rescale"), ("tc-grps", "Protein Non-Protein"), ("tau_t", "0.1 0.1"), ("ref_t", "300 300"),
+    ("pcoupl", "Parrinello-Rahman"), ("pcoupltype", "isotropic"), ("tau_p", "2.0"), ("ref_p", "1.0"), ("compressibility", "4.5e-5"),
+    ("pbc", "xyz"), ("DispCorr", "EnerPres"), ("gen_vel", "no"),
+]
+
+
+def write_cli_inputs(args, outdir):
+    """Child process of the command-line leg: the bench's own preparation (relax, equilibrate) on the GPU, then the
+    prepared system as the files `gmx grompp` reads: conf.gro, topol.top with its includes, state.cpt."""
+    import mdx  # noqa: F401
+    from mdx import ensemble
+    from mdx.io import gro, top, tpr
+    s = build_system(args)
+    seed = ensemble.replica_seed(20250829, 0)
+    e = engine_for(s, args, "relax", seed, 0); e.step(args.prep_steps); s1 = carry(s, e); e.close()
+    e = engine_for(s1, args, "equil", seed, 0); e.step(args.prep_steps); s2 = carry(s1, e); e.close()
+    top.write_top_tree(outdir, s2)
+    gro.write_system_gro(os.path.join(outdir, "conf.gro"), s2, x=s2.x, v=s2.v, box=s2.box)
+    tpr.save_checkpoint(os.path.join(outdir, "state.cpt"), 0, 0.0, s2.x, s2.v, s2.box)
+    return 0
+
+
+def cli_leg(args):
+    """The drop-in path, timed: the prepared system goes through `gmx grompp` and `gmx mdrun -deffnm prod -ntmpi 1 -ntomp 4`
+    (this repository's bin/gmx, the way /root/reference/Snakefile:311-315 runs the production stage) as child processes,
+    production.mdp's keys, 2 x --steps steps with -resethway, and the `Performance:` line of prod.log is what counts.
+    Called before this process touches the GPU; every GPU call of the leg happens in a child."""
+    import re
+    import shutil
+    import tempfile
+    gmx = os.path.join(ROOT, "bin", "gmx")
+    d = tempfile.mkdtemp(prefix="mdx_cli_leg_")
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    res = {"command": "gmx grompp -f production.mdp -c conf.gro -t state.cpt -p topol.top -o prod.tpr -maxwarn 1000 && "
+                      "gmx mdrun -v -deffnm prod -ntmpi 1 -ntomp 4 -resethway"}
+    try:
+        t0 = time.time()
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--write-cli-inputs", d, "--box", str(args.box), "--system", args.system,
+                            "--prep-steps", str(args.prep_steps)], capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            raise RuntimeError("input preparation failed: " + r.stderr[-400:])
+        nsteps = 2 * max(args.steps, 2500)
+        with open(os.path.join(d, "production.mdp"), "w") as f:
+            for k, v in PRODUCTION_MDP:
+                f.write("%-24s = %s\n" % (k, nsteps if v is None else v))
+        t1 = time.time()
+        r = subprocess.run([sys.executable, gmx, "grompp", "-f", "production.mdp", "-c", "conf.gro", "-t", "state.cpt", "-p", "topol.top",
+                            "-o", "prod.tpr", "-maxwarn", "1000"], cwd=d, capture_output=True, text=True, timeout=600, env=env)
+        if r.returncode != 0:
+            raise RuntimeError("grompp failed: " + (r.stderr or r.stdout)[-400:])
+        t2 = time.time()
+        r = subprocess.run([sys.executable, gmx, "mdrun", "-v", "-deffnm", "prod", "-ntmpi", "1", "-ntomp", "4", "-resethway"], cwd=d,
+                           capture_output=True, text=True, timeout=900, env=env)
+        t3 = time.time()
+        if r.returncode != 0:
+            raise RuntimeError("mdrun failed: " + (r.stderr or r.stdout)[-400:])
+        log = open(os.path.join(d, "prod.log")).read()
+        m = re.search(r"^Performance:\s+(\S+)\s+(\S+)", log, re.M)
+        if not m:
+            raise RuntimeError("no Performance line in prod.log")
+        files = {n: os.path.getsize(os.path.join(d, n)) for n in ("prod.xtc", "prod.edr", "prod.log", "prod.gro", "prod.cpt", "prod.trr")
+                 if os.path.exists(os.path.join(d, n))}
+        lst = re.search(r"pair-list radius: (\S+)\s+nstlist: (\d+)(?:\s+pruned every (\d+) steps to radius (\S+))?", log)
+        res.update({"cli_ns_per_day": float(m.group(1)), "hour_per_ns": float(m.group(2)), "nsteps": nsteps,
+                    "timed_steps": nsteps - nsteps // 2, "host_threads_for_output": 4,
+                    "grompp_s": round(t2 - t1, 2), "mdrun_process_s": round(t3 - t2, 2), "prepare_inputs_s": round(t1 - t0, 2),
+                    "outputs_MB": {n: round(v / 1e6, 2) for n, v in files.items()},
+                    "pair_list": lst.group(0) if lst else None})
+    except Exception as ex:          # the leg is a report beside `value`: its failure must not take the bench line with it
+        res["error"] = "%s: %s" % (type(ex).__name__, ex)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return res
+
+
 def private_stdout():
     """The JSON line must be the only thing on stdout, but RCCL prints a version banner there when its communicator is
     created. File descriptor 1 is therefore pointed at stderr for the life of the process (C libraries included) and the
@@ -187,16 +270,18 @@ def main():
                     help="dual pair list: the list of --nstlist steps is pruned to the pairs within the short-lived radius every "
                          "this many steps (0: one list; default 10 with the default --nstlist)")
     ap.add_argument("--nb-chunk", type=int, default=0, help="diagnostic: list entries per nonbonded work unit (0: the library's 32)")
+    ap.add_argument("--no-cli", action="store_true", help="skip the leg that times the same workload through bin/gmx grompp + mdrun")
+    ap.add_argument("--write-cli-inputs", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-steps", type=int, default=50, help="steps of the CPU baseline per thread count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prep-steps", type=int, default=2000)
     ap.add_argument("--no-output", action="store_true", help="diagnostic: skip the trajectory output the .mdp asks for")
     ap.add_argument("--chunk", type=int, default=0, help="diagnostic with --no-output: steps per mdx_step call")
     ap.add_argument("--ring", type=int, default=8, help="pinned trajectory-frame slots between the GPU and the encoder threads")
-    ap.add_argument("--encoders", type=int, default=2, help="frames compressed at the same time (host threads)")
-    ap.add_argument("--encoder-threads", type=int, default=0,
-                    help="threads that share the compression of one frame (segments); 0: 12 for one rank (they keep the drain of the "
-                         "last frame, which a short timed window sees in full, at 0.2 ms), 4 per rank when several ranks share the host")
+    ap.add_argument("--encoders", type=int, default=1, help="frames compressed at the same time")
+    ap.add_argument("--encoder-threads", type=int, default=4,
+                    help="host threads that share the bit packing of one frame (segments). The defaults use four host threads "
+                         "for output, what the pipeline grants mdrun (-ntomp 4): one frame at a time on four threads")
     ap.add_argument("--prime-steps", type=int, default=400,
                     help="un-timed steps before the warmup that run every kernel variant, pair searches, the coupling steps and the "
                          "frame pipeline (first launches and first frames carry one-off costs of milliseconds), and that bring the GPU "
@@ -211,6 +296,13 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)
+    if args.write_cli_inputs:
+        return write_cli_inputs(args, args.write_cli_inputs)
+    # the command-line leg runs first, in child processes, while this process has not touched the GPU yet
+    cli = None
+    if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and args.workload == "production" and not args.no_cli
+            and not args.no_output and args.system == "complex"):
+        cli = cli_leg(args)
     global JSON_OUT
     JSON_OUT = private_stdout()
     import torch
@@ -222,8 +314,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local)
-    if args.encoder_threads <= 0:
-        args.encoder_threads = 12 if world == 1 else 4
+    args.encoder_threads = max(1, args.encoder_threads)
     use_dist = world > 1 or bool(os.environ.get("MDX_BENCH_FORCE_DIST"))     # the latter: rehearsal of the N>1 code path on one GPU
     ctl = None
     if use_dist and (args.workload == "dd" or os.environ.get("MDX_BENCH_EAGER_RCCL")):      # (the latter: diagnostic)
@@ -285,9 +376,7 @@ def main():
             done = 0
             while done < nsteps:
                 if (e.get_step() % nst_xtc) == 0:
-                    slot = pipe.acquire_slot()
-                    e.capture_frame(slot)
-                    pipe.submit(slot, True, False, False)
+                    pipe.capture(True, False, False)
                 n = min(nsteps - done, nst_xtc - e.get_step() % nst_xtc)
                 e.step(n)
                 done += n
@@ -346,6 +435,10 @@ def main():
     if pipe is not None and pipe.stats["frames"]:
         nf = pipe.stats["frames"]
         phases["per_frame_ms"] = {k[:-2]: round(v / nf * 1e3, 3) for k, v in pipe.stats.items() if k.endswith("_s")}
+        if "last" in pipe.stats:      # the last frame's way through the encoder, milliseconds from the start of the timed region
+            phases["last_frame_ms"] = dict(zip(("dequeued", "copy_landed", "packed", "committed"),
+                                               [round((t - t0) * 1e3, 3) for t in pipe.stats["last"]]))
+            phases["gpu_done_ms"] = round((t_gpu - t0) * 1e3, 3)
     xtc_frames = xtc.frames if xtc is not None else 0
     xtc_bytes = os.path.getsize(xtc_path) if xtc_path else 0
     if pipe is not None and pipe.error is not None:
@@ -430,6 +523,9 @@ def main():
         }
         if smd:
             out["smd"] = smd
+        if cli is not None:
+            out["cli"] = cli
+            out["cli_ns_per_day"] = cli.get("cli_ns_per_day")
         if not args.no_cpu_baseline and world == 1:
             s3 = carry(s2, e)
             # 4 threads as the pipeline runs gmx mdrun (-ntomp 4, /root/reference/Snakefile:232-233), and the cores of this job

@@ -207,6 +207,14 @@ int mdx_frame_ring(mdx_system *sys, int nslots);
 int mdx_capture_frame(mdx_system *sys, int slot, int want_v);
 int mdx_frame_wait(mdx_system *sys, int slot, const float **x, const float **v, double *box9,
                    long long *step);
+/* The capture for `nstxout-compressed` frames (/root/reference/mdp/production.mdp:12-13): the positions arrive as the
+ * integers of the xtc coordinate block, l = (int)(x * precision +- 0.5) in single precision as the host encoder
+ * rounds them (`compressed-x-precision`, default 1000), with the frame's statistics stats8 = extent minimum (3),
+ * extent maximum (3), smallest sum of absolute differences between neighbouring atoms, flag (1: a coordinate is
+ * not finite or does not fit an int). The host is left with the bit packing. Velocities, box and step as above. */
+int mdx_capture_frame_xtc(mdx_system *sys, int slot, int want_v, float precision);
+int mdx_frame_wait_xtc(mdx_system *sys, int slot, const int **ix, const float **v, double *box9,
+                       long long *step, int *stats8);
 
 /* ---- compute */
 /* Single-point forces and energies of the selected terms at the current positions (rebuilds

@@ -6,6 +6,7 @@
 // (/root/reference/mdp/em_complex.mdp:3-6) and the output cadence keys `nstxout`,
 // `nstvout`, `nstxout-compressed` (/root/reference/mdp/production.mdp:7-12) switch on in gmx mdrun.
 #include "mdx_internal.h"
+#include <climits>
 #include <hip/hip_ext.h>
 #include <algorithm>
 #include <cmath>
@@ -226,8 +227,75 @@ __global__ __launch_bounds__(256) void k_unpack3(int n, const float4 *__restrict
     out[3 * i] = p.x; out[3 * i + 1] = p.y; out[3 * i + 2] = p.z;
 }
 
-struct FrameSlot { float *x = nullptr, *v = nullptr; double *box = nullptr; hipEvent_t ev = nullptr, ev_staged = nullptr; long long step = -1; int has_v = 0; };
-struct FrameRing { std::vector<FrameSlot> slots; float *d_stage = nullptr; double *d_box = nullptr; };
+// Capture for the compressed trajectory: the rounding pass of the xtc coordinate block on the GPU. Per atom
+// l = (int)(x * precision +- 0.5) in single precision (separately rounded multiply and add, as the host encoder computes
+// it), per frame the extent of the integers, the smallest sum of absolute differences between neighbouring atoms (it
+// selects the first entry of the format's small-number table) and a flag for a coordinate that is not finite or does
+// not fit; the host is left with the bit packing (csrc/trajio.cpp, trj_xtc_encode_frame_q).
+// stats: min x y z, max x y z, smallest neighbour difference, flag (set up by k_frame_stats_init).
+__global__ void k_frame_stats_init(int *__restrict__ stats)
+{
+    const int t = threadIdx.x;
+    if (t < 3) stats[t] = INT_MAX; else if (t < 6) stats[t] = INT_MIN; else if (t == 6) stats[t] = INT_MAX; else if (t == 7) stats[t] = 0;
+}
+
+__device__ __forceinline__ bool xtc_round(float xf, float precision, int &l)
+{
+    const float lf = __fmul_rn(xf, precision);
+    if (!(fabsf(lf) <= (float)(INT_MAX - 2))) { l = 0; return false; }       // also catches NaN
+    l = (int)(lf >= 0.0f ? __fadd_rn(lf, 0.5f) : __fsub_rn(lf, 0.5f));
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_frame_quantize(int n, const float4 *__restrict__ a, float precision, int *__restrict__ out,
+                                                        int *__restrict__ stats, const double *__restrict__ boxd,
+                                                        double *__restrict__ box_out)
+{
+    __shared__ int red[8][4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 9 && box_out) box_out[i] = boxd[i];
+    int mn[3] = { INT_MAX, INT_MAX, INT_MAX }, mx[3] = { INT_MIN, INT_MIN, INT_MIN }, md = INT_MAX, bad = 0;
+    if (i < n) {
+        const float4 p = a[i];
+        int l[3];
+        const bool ok = xtc_round(p.x, precision, l[0]) & xtc_round(p.y, precision, l[1]) & xtc_round(p.z, precision, l[2]);
+        if (!ok) bad = 1;
+        else {
+            for (int d = 0; d < 3; d++) { mn[d] = l[d]; mx[d] = l[d]; }
+            out[3 * (size_t)i] = l[0]; out[3 * (size_t)i + 1] = l[1]; out[3 * (size_t)i + 2] = l[2];
+            if (i > 0) {
+                const float4 q = a[i - 1];
+                int o[3];
+                if (xtc_round(q.x, precision, o[0]) & xtc_round(q.y, precision, o[1]) & xtc_round(q.z, precision, o[2])) {
+                    const long long diff = llabs((long long)o[0] - l[0]) + llabs((long long)o[1] - l[1]) + llabs((long long)o[2] - l[2]);
+                    md = (int)(diff < (long long)INT_MAX ? diff : (long long)INT_MAX);
+                }
+            }
+        }
+    }
+    // eight values per thread -> per wave (shuffles) -> per workgroup (LDS) -> eight atomics per workgroup
+    int v[8] = { mn[0], mn[1], mn[2], mx[0], mx[1], mx[2], md, bad };
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        for (int o = 32; o; o >>= 1) {
+            const int w = __shfl_xor(v[k], o, 64);
+            v[k] = (k >= 3 && k < 6) || k == 7 ? max(v[k], w) : min(v[k], w);
+        }
+        if (lane == 0) red[k][wv] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const int k = threadIdx.x;
+        const bool is_max = (k >= 3 && k < 6) || k == 7;
+        int r = red[k][0];
+        for (int w = 1; w < 4; w++) r = is_max ? max(r, red[k][w]) : min(r, red[k][w]);
+        if (is_max) atomicMax(&stats[k], r); else atomicMin(&stats[k], r);
+    }
+}
+
+struct FrameSlot { float *x = nullptr, *v = nullptr; double *box = nullptr; int *stats = nullptr; hipEvent_t ev = nullptr, ev_staged = nullptr; long long step = -1; int has_v = 0; int quantized = 0; };
+struct FrameRing { std::vector<FrameSlot> slots; float *d_stage = nullptr; double *d_box = nullptr; int *d_stats = nullptr; };
 static FrameRing *ring_of(mdx_system *s) { return (FrameRing *)s->frame_ring; }
 
 void mdx_frames_free(mdx_system *s)
@@ -238,11 +306,13 @@ void mdx_frames_free(mdx_system *s)
         if (f.x) (void)hipHostFree(f.x);
         if (f.v) (void)hipHostFree(f.v);
         if (f.box) (void)hipHostFree(f.box);
+        if (f.stats) (void)hipHostFree(f.stats);
         if (f.ev) (void)hipEventDestroy(f.ev);
         if (f.ev_staged) (void)hipEventDestroy(f.ev_staged);
     }
     if (r->d_stage) (void)hipFree(r->d_stage);
     if (r->d_box) (void)hipFree(r->d_box);
+    if (r->d_stats) (void)hipFree(r->d_stats);
     delete r;
     s->frame_ring = nullptr;
 }
@@ -260,16 +330,18 @@ extern "C" int mdx_frame_ring(mdx_system *s, int nslots)
         MDX_CHECK(s, hipHostMalloc((void **)&f.x, bytes, hipHostMallocDefault));
         MDX_CHECK(s, hipHostMalloc((void **)&f.v, bytes, hipHostMallocDefault));
         MDX_CHECK(s, hipHostMalloc((void **)&f.box, sizeof(double) * 9, hipHostMallocDefault));
+        MDX_CHECK(s, hipHostMalloc((void **)&f.stats, sizeof(int) * 8, hipHostMallocDefault));
         MDX_CHECK(s, hipEventCreateWithFlags(&f.ev, hipEventDisableTiming));
         MDX_CHECK(s, hipEventCreateWithFlags(&f.ev_staged, hipEventDisableTiming));
     }
     // one staging buffer per slot so that consecutive captures do not wait for each other
     MDX_CHECK(s, hipMalloc((void **)&r->d_stage, 2 * bytes * nslots));
     MDX_CHECK(s, hipMalloc((void **)&r->d_box, sizeof(double) * 9 * nslots));
+    MDX_CHECK(s, hipMalloc((void **)&r->d_stats, sizeof(int) * 8 * nslots));
     return MDX_OK;
 }
 
-extern "C" int mdx_capture_frame(mdx_system *s, int slot, int want_v)
+static int capture_frame(mdx_system *s, int slot, int want_v, bool quantize, float precision)
 {
     (void)hipSetDevice(s->device);
     FrameRing *r = ring_of(s);
@@ -279,18 +351,34 @@ extern "C" int mdx_capture_frame(mdx_system *s, int slot, int want_v)
     const size_t cnt = 3 * (size_t)n;
     float *dx = r->d_stage + 2 * cnt * slot, *dv = dx + cnt;
     double *dbox = r->d_box + 9 * slot;
+    int *dstats = r->d_stats + 8 * slot;
     if (want_v) hipLaunchKernelGGL(k_unpack3, dim3(nb), dim3(256), 0, s->stream, n, s->v, dv, nullptr, nullptr);
-    hipExtLaunchKernelGGL(k_unpack3, dim3(nb), dim3(256), 0, s->stream, nullptr, f.ev_staged, 0, n, (const float4 *)s->x, dx,
-                          (const double *)s->d->boxd, dbox);
+    if (quantize) {
+        hipLaunchKernelGGL(k_frame_stats_init, dim3(1), dim3(64), 0, s->stream, dstats);
+        hipExtLaunchKernelGGL(k_frame_quantize, dim3(nb), dim3(256), 0, s->stream, nullptr, f.ev_staged, 0, n, (const float4 *)s->x,
+                              precision, (int *)dx, dstats, (const double *)s->d->boxd, dbox);
+    } else {
+        hipExtLaunchKernelGGL(k_unpack3, dim3(nb), dim3(256), 0, s->stream, nullptr, f.ev_staged, 0, n, (const float4 *)s->x, dx,
+                              (const double *)s->d->boxd, dbox);
+    }
     MDX_CHECK(s, hipGetLastError());
     hipStream_t cs = s->st_bond;
     MDX_CHECK(s, hipStreamWaitEvent(cs, f.ev_staged, 0));
     MDX_CHECK(s, hipMemcpyAsync(f.x, dx, sizeof(float) * cnt, hipMemcpyDeviceToHost, cs));
     if (want_v) MDX_CHECK(s, hipMemcpyAsync(f.v, dv, sizeof(float) * cnt, hipMemcpyDeviceToHost, cs));
     MDX_CHECK(s, hipMemcpyAsync(f.box, dbox, sizeof(double) * 9, hipMemcpyDeviceToHost, cs));
+    if (quantize) MDX_CHECK(s, hipMemcpyAsync(f.stats, dstats, sizeof(int) * 8, hipMemcpyDeviceToHost, cs));
     MDX_CHECK(s, hipEventRecord(f.ev, cs));
-    f.step = s->step; f.has_v = want_v ? 1 : 0;
+    f.step = s->step; f.has_v = want_v ? 1 : 0; f.quantized = quantize ? 1 : 0;
     return MDX_OK;
+}
+
+extern "C" int mdx_capture_frame(mdx_system *s, int slot, int want_v) { return capture_frame(s, slot, want_v, false, 0.0f); }
+
+extern "C" int mdx_capture_frame_xtc(mdx_system *s, int slot, int want_v, float precision)
+{
+    ARG_CHECK(s, precision > 0.0f, "mdx_capture_frame_xtc: precision must be positive");
+    return capture_frame(s, slot, want_v, true, precision);
 }
 
 // Blocks until the capture into `slot` has landed; the pointers stay valid until the slot is
@@ -301,11 +389,29 @@ extern "C" int mdx_frame_wait(mdx_system *s, int slot, const float **x, const fl
     ARG_CHECK(s, r && slot >= 0 && slot < (int)r->slots.size(), "mdx_frame_wait: bad slot");
     FrameSlot &f = r->slots[slot];
     ARG_CHECK(s, f.step >= 0, "mdx_frame_wait: nothing captured in this slot");
+    ARG_CHECK(s, !f.quantized, "mdx_frame_wait: the slot holds xtc integers (mdx_frame_wait_xtc)");
     (void)hipSetDevice(s->device);
     if (hipEventSynchronize(f.ev) != hipSuccess) { return MDX_ERR_HIP; }
     if (x) *x = f.x;
     if (v) *v = f.has_v ? f.v : nullptr;
     if (box9) memcpy(box9, f.box, sizeof(double) * 9);
     if (step) *step = f.step;
+    return MDX_OK;
+}
+
+// The same for a slot captured with mdx_capture_frame_xtc: integer coordinates and the frame's eight statistics.
+extern "C" int mdx_frame_wait_xtc(mdx_system *s, int slot, const int **ix, const float **v, double *box9, long long *step, int *stats8)
+{
+    FrameRing *r = ring_of(s);
+    ARG_CHECK(s, r && slot >= 0 && slot < (int)r->slots.size(), "mdx_frame_wait_xtc: bad slot");
+    FrameSlot &f = r->slots[slot];
+    ARG_CHECK(s, f.step >= 0 && f.quantized, "mdx_frame_wait_xtc: no xtc capture in this slot");
+    (void)hipSetDevice(s->device);
+    if (hipEventSynchronize(f.ev) != hipSuccess) { return MDX_ERR_HIP; }
+    if (ix) *ix = (const int *)f.x;
+    if (v) *v = f.has_v ? f.v : nullptr;
+    if (box9) memcpy(box9, f.box, sizeof(double) * 9);
+    if (step) *step = f.step;
+    if (stats8) memcpy(stats8, f.stats, sizeof(int) * 8);
     return MDX_OK;
 }

@@ -21,6 +21,7 @@
 #include <string.h>
 #include <limits.h>
 #include <math.h>
+#include <time.h>
 #include <vector>
 #include <atomic>
 #include <thread>
@@ -43,7 +44,9 @@ static const int kLastIdx = (int)(sizeof(kMagic) / sizeof(kMagic[0]));
 static const float kMaxAbs = (float)(INT_MAX - 2);
 
 // ---------------------------------------------------------------- bit stream (MSB first)
-struct BitWriter {
+// (aligned to two cache lines: the writers of a frame's segments sit side by side in one array and every put updates
+// len / acc / nacc; sharing a line made three or more segment threads slower than one thread for the whole frame)
+struct alignas(128) BitWriter {
     std::vector<unsigned char> buf;     // sized up front by the caller for the worst case (no growth checks in put)
     size_t len = 0;
     uint64_t acc = 0;                   // low `nacc` bits are pending, nacc < 8 between calls
@@ -250,6 +253,8 @@ extern "C" {
 
 // segments of multi-threaded frames that had to be encoded again from the true state (diagnostic counter)
 static std::atomic<long long> g_xtc_respeculated{0};
+static thread_local double g_xtc_phase[4 + 16] = { 0 };   // last frame packed by this thread: segments, merge, copy-out, workers' longest (ms)
+static double now_ms() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 static int g_xtc_warm = 2048;      // atoms a segment's thread walks through, without output, ahead of its segment
 
 // ---------------------------------------------------------------- xtc run encoder
@@ -347,6 +352,9 @@ static void xtc_encode_range(const int *ip, int natoms, const XtcParams &P, XtcS
 }
 
 // ---------------------------------------------------------------- xtc coordinate block
+static int xtc_pack_coords(std::vector<unsigned char> &o, int natoms, const int *ip, const int *minint, const int *maxint, int mindiff,
+                           int nthreads);
+
 // Appends `natoms` (int), and the raw or compressed coordinates to `o`.
 static int xtc_encode_coords(std::vector<unsigned char> &o, int natoms, const float *x, float precision, int nthreads)
 {
@@ -396,6 +404,15 @@ static int xtc_encode_coords(std::vector<unsigned char> &o, int natoms, const fl
             if (md[k] < mindiff) mindiff = md[k];
         }
     }
+    return xtc_pack_coords(o, natoms, ip, minint, maxint, mindiff, nthreads);
+}
+
+// The part of the coordinate block behind the precision: extents, first small-number index, and the bit stream of the
+// integer coordinates `ip` (3 per atom, already rounded; extents and smallest neighbour distance as the rounding pass
+// found them, on the host above or on the GPU).
+static int xtc_pack_coords(std::vector<unsigned char> &o, int natoms, const int *ip, const int *minint, const int *maxint, int mindiff,
+                           int nthreads)
+{
     for (int d = 0; d < 3; d++) xdr_put_u32(o, (uint32_t)minint[d]);
     for (int d = 0; d < 3; d++) xdr_put_u32(o, (uint32_t)maxint[d]);
     for (int d = 0; d < 3; d++) if ((float)maxint[d] - (float)minint[d] >= kMaxAbs) return TRJ_ERR_RANGE;
@@ -443,7 +460,10 @@ static int xtc_encode_coords(std::vector<unsigned char> &o, int natoms, const fl
         for (int k = 1; k < T; k++) { segw[k].len = 0; segw[k].acc = 0; segw[k].nacc = 0; segw[k].reserve_bytes(((size_t)natoms / T + 64) * 16 + 64); }
         BitWriter *const seg = segw.data();        // (a thread_local name inside the parallel region would mean each worker's own, empty, vector)
         BitWriter *const w0 = &w;
+        const double t_par0 = now_ms();
+        double worker_ms[16] = { 0 };
         run_slices(T, [&](int k) {
+            const double t_w0 = now_ms();
             const int b0 = (int)((long long)natoms * k / T), b1 = (k + 1 == T) ? natoms : (int)((long long)natoms * (k + 1) / T);
             XtcState st = st0;
             if (k > 0) {
@@ -454,7 +474,9 @@ static int xtc_encode_coords(std::vector<unsigned char> &o, int natoms, const fl
             assumed[k] = st;
             xtc_encode_range(ip, natoms, P, st, b1, k == 0 ? w0 : &seg[k]);
             ended[k] = st;
+            worker_ms[k] = now_ms() - t_w0;
         });
+        const double t_par1 = now_ms();
         for (int k = 1; k < T; k++) {
             const int b1 = (k + 1 == T) ? natoms : (int)((long long)natoms * (k + 1) / T);
             if (ended[k - 1].i >= b1 && k + 1 < T) {       // the predecessor ran past this whole segment (one long run): nothing of it is left
@@ -471,6 +493,9 @@ static int xtc_encode_coords(std::vector<unsigned char> &o, int natoms, const fl
             }
         }
         g_xtc_respeculated += respeculated;
+        g_xtc_phase[0] = t_par1 - t_par0; g_xtc_phase[1] = now_ms() - t_par1;
+        g_xtc_phase[3] = 0; for (int k = 0; k < T; k++) if (worker_ms[k] > g_xtc_phase[3]) g_xtc_phase[3] = worker_ms[k];
+        for (int k = 0; k < 16; k++) g_xtc_phase[4 + k] = k < T ? worker_ms[k] : 0.0;
     }
     const size_t nbytes = w.finish();
     xdr_put_u32(o, (uint32_t)nbytes);
@@ -506,6 +531,33 @@ long long trj_xtc_encode_frame(unsigned char *out, long long cap, int natoms, lo
                                const float *x, float precision)
 {
     return trj_xtc_encode_frame_mt(out, cap, natoms, step, time, box9, x, precision, 1);
+}
+
+// The same frame from coordinates that are rounded already (the engine's capture kernel multiplies by the precision
+// and rounds on the GPU): ix holds 3 integers per atom, stats8 = extent minimum (3), extent maximum (3), smallest sum of
+// absolute differences between neighbouring atoms, and a flag for a coordinate that is not finite or out of range.
+// The bytes are those trj_xtc_encode_frame_mt gives for the float coordinates. Frames of fewer than 10 atoms are
+// stored as floats by the format and cannot come this way.
+long long trj_xtc_encode_frame_q(unsigned char *out, long long cap, int natoms, long long step, float time, const float *box9,
+                                 const int *ix, const int *stats8, float precision, int nthreads)
+{
+    if (natoms <= 9) return TRJ_ERR_RANGE;
+    if (stats8[7] != 0) return TRJ_ERR_RANGE;
+    std::vector<unsigned char> o;
+    o.reserve((size_t)natoms * 5 + 128);
+    xdr_put_u32(o, 1995u);
+    xdr_put_u32(o, (uint32_t)natoms);
+    xdr_put_u32(o, (uint32_t)(int32_t)step);
+    xdr_put_f32(o, time);
+    for (int k = 0; k < 9; k++) xdr_put_f32(o, box9[k]);
+    xdr_put_u32(o, (uint32_t)natoms);
+    if (precision <= 0) precision = 1000.0f;
+    xdr_put_f32(o, precision);
+    const int rc = xtc_pack_coords(o, natoms, ix, stats8, stats8 + 3, stats8[6], nthreads);
+    if (rc != TRJ_OK) return rc;
+    if ((long long)o.size() > cap) return TRJ_ERR_RANGE;
+    memcpy(out, o.data(), o.size());
+    return (long long)o.size();
 }
 
 int trj_xtc_append(const char *path, int truncate, int natoms, long long step, float time, const float *box9, const float *x,
@@ -707,6 +759,9 @@ int trj_trr_decode_frame(const unsigned char *data, long long len, long long *us
 }
 
 long long trj_xtc_respeculated(void) { return g_xtc_respeculated.load(); }
+// Diagnostic: where the calling thread's last multi-threaded frame spent its time (ms): the parallel segments, the merge
+// of the segments, (unused), the slowest segment's own time.
+void trj_xtc_last_phases(double *out20) { for (int k = 0; k < 20; k++) out20[k] = g_xtc_phase[k]; }
 // Test hook: length of the warm-up walk (0 makes nearly every segment start from a wrong guess, which exercises the
 // path that encodes a segment again from the true state). Returns the previous value.
 int trj_xtc_set_warmup(int atoms) { const int old = g_xtc_warm; g_xtc_warm = atoms < 0 ? 0 : atoms; return old; }

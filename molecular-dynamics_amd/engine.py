@@ -36,7 +36,7 @@ SYMBOLS = [
     "mdx_dd_load", "mdx_dd_pack", "mdx_dd_unpack", "mdx_dd_step_begin", "mdx_dd_wait_spread", "mdx_dd_step_end", "mdx_dd_grid",
     "mdx_dd_stream_sync", "mdx_dd_state_pointers", "mdx_dd_streams", "mdx_dd_set_roles", "mdx_dd_scalars", "mdx_dd_tcouple", "mdx_dd_kinetic", "mdx_dd_com", "mdx_dd_pressure", "mdx_dd_pcouple",
     "mdx_debug_time_stage", "mdx_set_step", "mdx_generate_velocities", "mdx_constrain_start", "mdx_minimize",
-    "mdx_frame_ring", "mdx_capture_frame", "mdx_frame_wait",
+    "mdx_frame_ring", "mdx_capture_frame", "mdx_frame_wait", "mdx_capture_frame_xtc", "mdx_frame_wait_xtc",
 ]
 PROGRESS_FN = ctypes.CFUNCTYPE(None, ctypes.c_longlong, ctypes.c_double, ctypes.c_double, ctypes.c_double)
 
@@ -147,6 +147,8 @@ def load_library(path: str | None = None):
     L.mdx_frame_ring.argtypes = [vp, c_int]
     L.mdx_capture_frame.argtypes = [vp, c_int, c_int]
     L.mdx_frame_wait.argtypes = [vp, c_int, ctypes.POINTER(fp), ctypes.POINTER(fp), dp, llp]
+    L.mdx_capture_frame_xtc.argtypes = [vp, c_int, c_int, c_f]
+    L.mdx_frame_wait_xtc.argtypes = [vp, c_int, ctypes.POINTER(ip), ctypes.POINTER(fp), dp, llp, ip]
     for name in SYMBOLS:
         getattr(L, name)        # every declared entry point must be exported
     if path is None:
@@ -510,6 +512,23 @@ class Engine:
 
     def capture_frame(self, slot, want_v=False):
         self._call("mdx_capture_frame", int(slot), 1 if want_v else 0)
+
+    def capture_frame_xtc(self, slot, precision=1000.0, want_v=False):
+        """Capture with the xtc rounding done on the GPU (frame_wait_xtc fetches it)."""
+        self._call("mdx_capture_frame_xtc", int(slot), 1 if want_v else 0, ctypes.c_float(float(precision)))
+
+    def frame_wait_xtc(self, slot):
+        """-> (step, ix (N,3) int32 view of the pinned slot, v or None, box (3,3) f64, stats (8,) int32)."""
+        px = ctypes.POINTER(ctypes.c_int)(); pv = ctypes.POINTER(ctypes.c_float)()
+        box = np.zeros(9, np.float64); stats = np.zeros(8, np.int32)
+        st = ctypes.c_longlong(0)
+        rc = self.lib.mdx_frame_wait_xtc(self.h, int(slot), ctypes.byref(px), ctypes.byref(pv), _p(box, ctypes.c_double), ctypes.byref(st),
+                                         _p(stats, ctypes.c_int))
+        if rc != 0:
+            raise MdxError(f"mdx_frame_wait_xtc failed ({rc}): " + self.lib.mdx_last_error(self.h).decode())
+        ix = np.ctypeslib.as_array(px, shape=(self.n, 3))
+        v = np.ctypeslib.as_array(pv, shape=(self.n, 3)) if pv else None
+        return int(st.value), ix, v, box.reshape(3, 3), stats
 
     def frame_wait(self, slot):
         """-> (step, x (N,3) f32 view of the pinned slot, v or None, box (3,3) f64). The views

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libmdxio.so")
-SYMBOLS = ["trj_version", "trj_xtc_frame_bound", "trj_xtc_encode_frame", "trj_xtc_encode_frame_mt", "trj_xtc_respeculated", "trj_xtc_set_warmup", "trj_xtc_append", "trj_xtc_decode_frame",
+SYMBOLS = ["trj_version", "trj_xtc_frame_bound", "trj_xtc_encode_frame", "trj_xtc_encode_frame_mt", "trj_xtc_encode_frame_q", "trj_xtc_respeculated", "trj_xtc_set_warmup", "trj_xtc_append", "trj_xtc_decode_frame",
            "trj_trr_frame_bound", "trj_trr_encode_frame", "trj_trr_append", "trj_trr_decode_frame"]
 _LIB = None
 
@@ -36,6 +36,8 @@ def load_library():
     L.trj_xtc_encode_frame.argtypes = [ucp, c_ll, c_int, c_ll, c_f, fp, fp, c_f]
     L.trj_xtc_encode_frame_mt.restype = c_ll
     L.trj_xtc_encode_frame_mt.argtypes = [ucp, c_ll, c_int, c_ll, c_f, fp, fp, c_f, c_int]
+    L.trj_xtc_encode_frame_q.restype = c_ll
+    L.trj_xtc_encode_frame_q.argtypes = [ucp, c_ll, c_int, c_ll, c_f, fp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_f, c_int]
     L.trj_xtc_respeculated.restype = c_ll
     L.trj_xtc_append.argtypes = [ctypes.c_char_p, c_int, c_int, c_ll, c_f, fp, fp, c_f]
     L.trj_xtc_decode_frame.argtypes = [ucp, c_ll, ctypes.POINTER(c_ll), ctypes.POINTER(c_int), ctypes.POINTER(c_ll),
@@ -83,6 +85,23 @@ class XtcWriter:
             buf = tl.buf = (ctypes.c_ubyte * int(self.lib.trj_xtc_frame_bound(self.natoms)))()
         n = self.lib.trj_xtc_encode_frame_mt(buf, len(buf), self.natoms, int(step), float(time), _fptr(box), _fptr(x), self.precision,
                                              self.threads)
+        if n < 0:
+            raise TrajError(f"xtc encoding failed ({n}): coordinate out of range or not finite")
+        return bytes(memoryview(buf)[:n])
+
+    def encode_quantized(self, step: int, time: float, box, ix, stats) -> bytes:
+        """The frame from coordinates rounded already (the engine's xtc capture): same bytes as `encode` of the floats."""
+        ix = np.ascontiguousarray(ix, dtype=np.int32); stats = np.ascontiguousarray(stats, dtype=np.int32)
+        box = _f32(np.asarray(box).reshape(9))
+        if ix.shape != (self.natoms, 3):
+            raise TrajError(f"frame has shape {ix.shape}, expected ({self.natoms}, 3)")
+        tl = self._tls
+        buf = getattr(tl, "buf", None)
+        if buf is None:
+            buf = tl.buf = (ctypes.c_ubyte * int(self.lib.trj_xtc_frame_bound(self.natoms)))()
+        ipt = ctypes.POINTER(ctypes.c_int)
+        n = self.lib.trj_xtc_encode_frame_q(buf, len(buf), self.natoms, int(step), float(time), _fptr(box), ix.ctypes.data_as(ipt),
+                                            stats.ctypes.data_as(ipt), self.precision, self.threads)
         if n < 0:
             raise TrajError(f"xtc encoding failed ({n}): coordinate out of range or not finite")
         return bytes(memoryview(buf)[:n])

@@ -37,8 +37,22 @@ class FramePipeline:
         """Blocks while every slot still waits for its encoder (back-pressure on the step loop)."""
         return self.free.get()
 
+    def capture(self, want_xtc, want_trr_x, want_trr_v):
+        """Take a free slot, enqueue the capture of the current state into it and hand it to the encoders. A frame that goes
+        to the compressed trajectory only, whole system, is rounded to the xtc integers on the GPU (the encoder thread is
+        left with the bit packing); every other frame arrives as floats."""
+        slot = self.acquire_slot()
+        quant = bool(want_xtc and self.xtc is not None and self.sel is None and not want_trr_x and self.xtc.natoms > 9)
+        if quant:
+            self.eng.capture_frame_xtc(slot, self.xtc.precision, want_v=want_trr_v)
+        else:
+            self.eng.capture_frame(slot, want_v=want_trr_v)
+        self.q.put((self._seq, slot, want_xtc, want_trr_x, want_trr_v, quant))
+        self._seq += 1
+
     def submit(self, slot, want_xtc, want_trr_x, want_trr_v):
-        self.q.put((self._seq, slot, want_xtc, want_trr_x, want_trr_v))
+        """A slot the caller has captured into with Engine.capture_frame (floats)."""
+        self.q.put((self._seq, slot, want_xtc, want_trr_x, want_trr_v, False))
         self._seq += 1
 
     def _run(self):
@@ -46,15 +60,21 @@ class FramePipeline:
             item = self.q.get()
             if item is None:
                 return
-            seq, slot, wx, tx, tv = item
+            seq, slot, wx, tx, tv, quant = item
             xb = None
             args = None
             t_a = t_b = t_c = time.perf_counter()
             try:
-                step, x, v, box = self.eng.frame_wait(slot)
+                if quant:
+                    step, ix, v, box, stats = self.eng.frame_wait_xtc(slot)
+                    x = None
+                else:
+                    step, x, v, box = self.eng.frame_wait(slot)
                 t_b = time.perf_counter()
                 t = self.tinit + step * self.dt
-                if wx and self.xtc is not None:
+                if quant:
+                    xb = self.xtc.encode_quantized(step, t, box, ix, stats)
+                elif wx and self.xtc is not None:
                     xb = self.xtc.encode(step, t, box, x if self.sel is None else x[self.sel])
                 t_c = time.perf_counter()
                 if (tx or tv) and self.trr is not None:
@@ -75,6 +95,7 @@ class FramePipeline:
                     self.error = self.error or e
                 self._next_commit += 1
                 st = self.stats
+                st["last"] = (t_a, t_b, t_c, time.perf_counter())     # taken from the queue, copy landed, packed, committed
                 st["frames"] += 1; st["wait_s"] += t_b - t_a; st["encode_s"] += t_c - t_b; st["commit_s"] += time.perf_counter() - t_c
                 self._cv.notify_all()
 

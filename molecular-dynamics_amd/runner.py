@@ -389,6 +389,7 @@ def _mdrun_parser():
     p.add_argument("-append", action="store_true", default=True)
     p.add_argument("-noappend", dest="append", action="store_false")
     p.add_argument("-gpu_id", default=None)
+    p.add_argument("-resethway", action="store_true")
     for opt in ("-ntmpi", "-ntomp", "-nt", "-nb", "-pme", "-bonded", "-update", "-pin", "-pinoffset", "-maxh", "-dlb",
                 "-npme", "-ntomp_pme", "-pinstride", "-nstlist", "-tunepme"):
         p.add_argument(opt, default=None)
@@ -615,8 +616,15 @@ def mdrun(argv, out=sys.stdout, err=sys.stderr) -> int:
             from .io import traj
             if not appending:
                 _backup(f_xtc)
+            # `-ntomp` host threads are what the pipeline grants mdrun (/root/reference/Snakefile:232-233): up to four of them
+            # share the bit packing of one frame (a whole-system frame of the production cadence is due every 1.7 ms and
+            # takes one core about 3 ms), further ones pack further frames at the same time
+            try:
+                ntomp = max(1, min(int(a.ntomp), 64)) if a.ntomp else 4
+            except ValueError:
+                ntomp = 4
             xtc = traj.XtcWriter(f_xtc, sysm.natoms if sel is None else len(sel), precision=m.f("compressed_x_precision"),
-                                 append=appending, threads=4)
+                                 append=appending, threads=min(ntomp, 4))
         if nst_x > 0 or nst_v > 0:
             from .io import traj
             if not appending:
@@ -627,7 +635,7 @@ def mdrun(argv, out=sys.stdout, err=sys.stderr) -> int:
         if xtc is not None or trr is not None:
             eng.frame_ring(nslots)
             from .output import FramePipeline
-            writer = FramePipeline(eng, nslots, xtc, trr, sel, dt, tinit, nthreads=2)
+            writer = FramePipeline(eng, nslots, xtc, trr, sel, dt, tinit, nthreads=max(1, min(ntomp // 4, nslots)) if xtc is not None else 1)
         if not appending:
             _backup(f_edr)
         edr = enio.EdrWriter(f_edr, append=appending, dt_ps=dt)
@@ -641,9 +649,7 @@ def mdrun(argv, out=sys.stdout, err=sys.stderr) -> int:
                 return          # the part that ended here already wrote this step's frame
             wx, tx, tv = due(nst_xtc, s) and xtc is not None, due(nst_x, s), due(nst_v, s)
             if writer is not None and (wx or tx or tv):
-                slot = writer.acquire_slot()
-                eng.capture_frame(slot, want_v=tv)
-                writer.submit(slot, wx, tx, tv)
+                writer.capture(wx, tx, tv)
 
         def drain():
             for fr in eng.pop_energy_frames():
@@ -677,7 +683,15 @@ def mdrun(argv, out=sys.stdout, err=sys.stderr) -> int:
         out.write(f"starting mdrun '{sysm.title}'\n{nsteps} steps, {nsteps * dt:8.1f} ps"
                   + (f" (continuing from step {step0}, {step0 * dt:8.1f} ps).\n" if step0 else ".\n"))
         out.flush()
+        reset_pending = bool(a.resethway) and nsteps - step0 >= 2
         while step < nsteps and not stop["flag"]:
+            if reset_pending and step - step0 >= (nsteps - step0) // 2:
+                # `-resethway`: the performance figure of the log covers the second half of the run only
+                eng.synchronize()
+                if writer is not None:
+                    writer.wait_idle()
+                t_loop0 = time.time(); steps_run = 0; reset_pending = False
+                log.note(f"\nStep {step}: resetting all time and cycle counters")
             maybe_capture(step)
             nxt = min(nsteps, step + chunk_cap)
             for c in cadences:

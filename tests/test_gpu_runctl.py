@@ -2,6 +2,8 @@
 (`gen_vel`, /root/reference/mdp/nvt_complex.mdp:39-41), constraining the start (`continuation = no`,
 nvt_complex.mdp:13), steepest descent (/root/reference/mdp/em_complex.mdp:3-6), the step counter
 used by checkpoint restarts, and the asynchronous trajectory-frame ring."""
+import os
+
 import numpy as np
 import pytest
 
@@ -139,3 +141,51 @@ def test_step_counter_and_frame_ring(small_water):
             e4.capture_frame(0)
         finally:
             e4.close()
+
+
+def test_xtc_capture_rounds_on_the_gpu_like_the_host_encoder(small_complex, tmp_path):
+    """`nstxout-compressed` frames (/root/reference/mdp/production.mdp:12-13) captured as xtc integers: the same state
+    captured both ways gives the same integers as the host rounding, the same frame statistics, and a byte-identical
+    frame; then the output pipeline with device-rounded frames against the same run written from float captures."""
+    from mdx.io import traj
+    from mdx.output import FramePipeline
+    from test_io_formats import xtc_round_like_the_capture_kernel
+    s = small_complex
+    e = eng.Engine(s, rc=1.0, nstcalcenergy=0, tc_groups=["System"], ref_t=[300.0], tau_t=[0.1], seed=3)
+    e.frame_ring(4)
+    e.step(9)
+    e.capture_frame(0)
+    e.capture_frame_xtc(1, 1000.0, want_v=True)
+    e.step(2)
+    st0, x, _, box0 = e.frame_wait(0)
+    st1, ix, v, box1, stats = e.frame_wait_xtc(1)
+    assert st0 == st1 == 9 and v is not None and np.array_equal(box0, box1)
+    want_ix, want_stats = xtc_round_like_the_capture_kernel(x)
+    assert np.array_equal(ix, want_ix)
+    assert np.array_equal(stats, want_stats)
+    w = traj.XtcWriter(os.devnull, s.natoms, threads=2)
+    assert w.encode_quantized(st1, 0.018, box1, ix, stats) == w.encode(st0, 0.018, box0, x)
+    with pytest.raises(eng.MdxError):
+        e.frame_wait(1)                  # a slot of integers is not handed out as floats
+    e.close()
+    # the pipeline: frames every 5 steps, device-rounded (capture) against float captures (submit), same run
+    files = []
+    for quant in (True, False):
+        e = eng.Engine(s, rc=1.0, nstcalcenergy=0, nstlist=10)
+        e.frame_ring(4)
+        p = str(tmp_path / ("q%d.xtc" % quant))
+        xw = traj.XtcWriter(p, s.natoms, threads=2)
+        pipe = FramePipeline(e, 4, xw, None, None, 0.002, 0.0, nthreads=2)
+        for _ in range(4):
+            if quant:
+                pipe.capture(True, False, False)
+            else:
+                slot = pipe.acquire_slot(); e.capture_frame(slot); pipe.submit(slot, True, False, False)
+            e.step(5)
+        e.synchronize(); pipe.finish(); xw.close(); e.close()
+        assert pipe.error is None
+        files.append(traj.read_xtc(p))
+    assert [f["step"] for f in files[0]] == [0, 5, 10, 15] == [f["step"] for f in files[1]]
+    assert np.array_equal(files[0][0]["x"], files[1][0]["x"])                 # the same start state, rounded on either side
+    for a, b in zip(files[0], files[1]):
+        assert np.abs(a["x"] - b["x"]).max() < 2.1e-3                         # two runs: float atomics, then rounding to 1e-3

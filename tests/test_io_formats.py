@@ -539,6 +539,39 @@ def test_xtc_threaded_encoder_gives_the_same_bytes():
     assert np.abs(fr[0]["x"] - wat).max() <= 0.501e-3
 
 
+def xtc_round_like_the_capture_kernel(x, precision=1000.0):
+    """The rounding pass of the xtc coordinate block as the engine's capture kernel does it (single precision, multiply
+    and add rounded separately): integer coordinates and the eight frame statistics."""
+    lf = x.astype(np.float32) * np.float32(precision)
+    ix = np.where(lf >= 0, lf + np.float32(0.5), lf - np.float32(0.5)).astype(np.float32).astype(np.int32)
+    d = np.abs(np.diff(ix.astype(np.int64), axis=0)).sum(1)
+    stats = np.array(list(ix.min(0)) + list(ix.max(0)) + [int(d.min()), 0], dtype=np.int32)
+    return ix, stats
+
+
+def test_xtc_frame_from_rounded_coordinates_gives_the_same_bytes():
+    """trj_xtc_encode_frame_q (bit packing only, coordinates rounded beforehand) against the encoder that starts from
+    the floats, on one and on several threads."""
+    import mdx  # noqa: F401
+    from mdx import synth
+    from mdx.io import traj
+    rng = np.random.default_rng(8)
+    wat = synth.water_box(d=5.0).x
+    frames = {"water": wat - 7.5, "gas": rng.uniform(-3, 30, size=(20000, 3)), "tight": rng.normal(0, 0.003, size=(12000, 3)) - 2}
+    box = np.diag([30.0, 30.0, 30.0])
+    for name, x in frames.items():
+        x = x.astype(np.float32)
+        ix, stats = xtc_round_like_the_capture_kernel(x)
+        for t in (1, 4):
+            w = traj.XtcWriter(os.devnull, len(x), threads=t)
+            assert w.encode_quantized(3, 0.006, box, ix, stats) == w.encode(3, 0.006, box, x), (name, t)
+    w = traj.XtcWriter(os.devnull, len(wat), threads=1)
+    ix, stats = xtc_round_like_the_capture_kernel(wat)
+    stats[7] = 1                         # the capture flagged a coordinate that does not fit
+    with pytest.raises(traj.TrajError):
+        w.encode_quantized(0, 0.0, box, ix, stats)
+
+
 # ------------------------------------------------------------------ the pipeline's own .mdp files, verbatim
 _REF_MDP = "/root/reference/mdp"
 
