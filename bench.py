@@ -350,8 +350,6 @@ def main():
     e = engine_for(s2, args, "run", seed, local)
     if args.nb_chunk:
         e.debug_set(14, args.nb_chunk)
-    if os.environ.get("MDX_NB_VARIANT"):      # diagnostic A/B of nonbonded launch shapes
-        e.debug_set(1, int(os.environ["MDX_NB_VARIANT"]))
     for kv in filter(None, os.environ.get("MDX_DEBUG", "").split(",")):     # diagnostic switches "key=value,..."
         e.debug_set(int(kv.split("=")[0]), int(kv.split("=")[1], 0))
     dt = e.dt

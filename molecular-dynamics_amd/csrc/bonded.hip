@@ -239,7 +239,7 @@ int mdx_launch_bonded(mdx_system *s, bool energy, unsigned flags)
     for (int k = 0; k < 5; k++) { A.nb[k] = acc; acc += (cnt[k] + 255) / 256; }
     A.nblocks = acc;
     if (acc == 0) return MDX_OK;
-    hipStream_t st = s->bond_on_main ? s->stream : s->st_bond;
+    hipStream_t st = s->st_bond;
     if (energy) hipLaunchKernelGGL(k_bonded<true>, dim3(acc), dim3(256), 0, st, A);
     else hipLaunchKernelGGL(k_bonded<false>, dim3(acc), dim3(256), 0, st, A);
     // the Ewald correction of excluded pairs is evaluated by the nonbonded kernel on the pair list

@@ -101,9 +101,7 @@ extern "C" mdx_system *mdx_create(int device, int natoms)
               hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_pme, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_bond, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
-              hipEventCreateWithFlags(&s->ev_spread, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
-              hipEventCreateWithFlags(&s->ev_nbdone, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
-              hipEventCreateWithFlags(&s->ev_tc, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
+              hipEventCreateWithFlags(&s->ev_spread, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
     s->own_streams[0] = s->stream; s->own_streams[1] = s->st_pme; s->own_streams[2] = s->st_bond;
     // MDX_STREAMS=1: every kernel of the handle on one stream (diagnostic; three streams are the default)
     if (const char *e = getenv("MDX_STREAMS")) if (atoi(e) == 1 && ok) (void)mdx_set_stream_mode(s, 1);
@@ -157,7 +155,7 @@ extern "C" void mdx_destroy(mdx_system *s)
                      s->col_count, s->col_astart, s->col_scstart, s->col_atoms, s->atom_col, s->atom_slot, s->wrapped, s->cj, s->work, s->work_order, s->sc_nwork,
                      s->exclmask, s->shift_ijk, s->shiftvec, s->bond_ij, s->bond_p, s->angle_ijk, s->angle_p, s->dih_ijkl, s->dih_p,
                      s->pair_ij, s->pair_p, s->posres_idx, s->posres_ref, s->posres_k, s->settle_idx, s->cons_ij, s->cons_len,
-                     s->comp_start, s->comp_atom_start, s->comp_atoms, s->comp_local, s->free_atoms, s->d_tc, s->pull_idx[0], s->pull_idx[1], s->gtab, s->htab, s->nut_tab, s->dd_q0, s->dd_invm0, s->dd_lj0,
+                     s->comp_start, s->comp_atom_start, s->comp_atoms, s->comp_local, s->free_atoms, s->d_tc, s->pull_idx[0], s->pull_idx[1], s->gtab, s->htab, s->dd_q0, s->dd_invm0, s->dd_lj0,
                      s->cj_in[0], s->cj_in[1], s->work_in[0], s->work_in[1], s->order_in[0], s->order_in[1], s->d };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (s->h) (void)hipHostFree(s->h);
@@ -168,8 +166,6 @@ extern "C" void mdx_destroy(mdx_system *s)
     if (s->ev_pme) (void)hipEventDestroy(s->ev_pme);
     if (s->ev_bond) (void)hipEventDestroy(s->ev_bond);
     if (s->ev_spread) (void)hipEventDestroy(s->ev_spread);
-    if (s->ev_nbdone) (void)hipEventDestroy(s->ev_nbdone);
-    if (s->ev_tc) (void)hipEventDestroy(s->ev_tc);
     for (hipStream_t st : s->own_streams) if (st) (void)hipStreamDestroy(st);
     delete s;
 }
@@ -185,7 +181,7 @@ int mdx_set_stream_mode(mdx_system *s, int one_stream)
     s->stream = s->own_streams[0];
     s->st_pme = s->one_stream ? s->own_streams[0] : s->own_streams[1];
     s->st_bond = s->one_stream ? s->own_streams[0] : s->own_streams[2];
-    s->pme_signalled = false; s->gather_pending = nullptr;
+    s->pme_signalled = false;
     return MDX_OK;
 }
 
@@ -431,40 +427,18 @@ extern "C" int mdx_set_nonbonded(mdx_system *s, float rc, float rlist, float bet
     }
     if (!s->htab) MDX_CHECK(s, hipMalloc((void **)&s->htab, sizeof(float4) * MDX_GTAB_N));
     MDX_CHECK(s, hipMemcpy(s->htab, tab4.data(), sizeof(float4) * MDX_GTAB_N, hipMemcpyHostToDevice));
-    // the force kernel's table carries beta^3 g (one multiplication less per pair), each interval as the line
-    // c0 + c1 t through its end points in the table coordinate t = r^2 N / rc^2 itself (no fractional part to take)
-    const double b3 = (double)beta * beta * beta;
-    for (int k = 0; k < MDX_GTAB_N; k++) {
-        const double g0 = g(wmax * k / MDX_GTAB_N), g1 = g(wmax * (k + 1) / MDX_GTAB_N);
-        const double c1 = b3 * (g1 - g0);
-        tab[k] = make_float2((float)(b3 * g0 - c1 * k), (float)c1);
-    }
-    if (!s->gtab) MDX_CHECK(s, hipMalloc((void **)&s->gtab, sizeof(float2) * MDX_GTAB_N));
-    MDX_CHECK(s, hipMemcpy(s->gtab, tab.data(), sizeof(float2) * MDX_GTAB_N, hipMemcpyHostToDevice));
-    // Force table on the leading bits of r^2: 512 intervals per binade from r^2 = 2^-7 nm^2 (r = 0.088 nm, below any
-    // contact of non-excluded atoms and below the intramolecular distances of excluded pairs) to rc^2. Per interval the
-    // lines a0 + a1 w ~ 1/w and c0 + c1 w ~ w^-3/2 - beta^3 g(beta^2 w): the chord through the end points moved by
-    // half its largest deviation (both functions are convex), relative error 5e-7 and 9e-7.
+    // The force kernel's table carries beta^3 g (one multiplication less per pair), each interval as the line c0 + c1 r^2
+    // through its end points, written in r^2 itself (no table coordinate, no fractional part to take per pair).
     {
-        const float wlo = 0.0078125f;
-        uint32_t lo_bits, hi_bits; const float rc2f = rc * rc;
-        memcpy(&lo_bits, &wlo, 4); memcpy(&hi_bits, &rc2f, 4);
-        const int n = (int)((hi_bits - lo_bits) >> 14) + 1;
-        std::vector<float4> nt(n);
-        auto fa = [](double w) { return 1.0 / w; };
-        auto fc = [&](double w) { return 1.0 / (w * sqrt(w)) - b3 * g((double)beta * beta * w); };
-        for (int k = 0; k < n; k++) {
-            uint32_t b0 = lo_bits + ((uint32_t)k << 14), b1 = b0 + (1u << 14);
-            float w0f, w1f; memcpy(&w0f, &b0, 4); memcpy(&w1f, &b1, 4);
-            const double w0 = w0f, w1 = w1f, wm = 0.5 * (w0 + w1);
-            const double a1 = (fa(w1) - fa(w0)) / (w1 - w0), a0 = fa(w0) - a1 * w0 + 0.5 * (fa(wm) - (fa(w0) + a1 * (wm - w0)));
-            const double c1 = (fc(w1) - fc(w0)) / (w1 - w0), c0 = fc(w0) - c1 * w0 + 0.5 * (fc(wm) - (fc(w0) + c1 * (wm - w0)));
-            nt[k] = make_float4((float)a0, (float)a1, (float)c0, (float)c1);
+        const double b3 = (double)beta * beta * beta;
+        const double scale = (double)MDX_GTAB_N / ((double)rc * rc);
+        for (int k = 0; k < MDX_GTAB_N; k++) {
+            const double g0 = g(wmax * k / MDX_GTAB_N), g1 = g(wmax * (k + 1) / MDX_GTAB_N);
+            const double c1 = b3 * (g1 - g0);
+            tab[k] = make_float2((float)(b3 * g0 - c1 * k), (float)(c1 * scale));
         }
-        if (s->nut_tab) { (void)hipFree(s->nut_tab); s->nut_tab = nullptr; }
-        MDX_CHECK(s, hipMalloc((void **)&s->nut_tab, sizeof(float4) * n));
-        MDX_CHECK(s, hipMemcpy(s->nut_tab, nt.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
-        s->nut_n = n; s->nut_lo = lo_bits;
+        if (!s->gtab) MDX_CHECK(s, hipMalloc((void **)&s->gtab, sizeof(float2) * MDX_GTAB_N));
+        MDX_CHECK(s, hipMemcpy(s->gtab, tab.data(), sizeof(float2) * MDX_GTAB_N, hipMemcpyHostToDevice));
     }
     return MDX_OK;
 }
@@ -757,7 +731,7 @@ int mdx_join(mdx_system *s)
     MDX_CHECK(s, hipEventRecord(s->ev_bond, s->st_bond));
     MDX_CHECK(s, hipStreamWaitEvent(s->stream, s->ev_bond, 0));
     MDX_CHECK(s, hipStreamWaitEvent(s->stream, s->ev_pme, 0));
-    return mdx_launch_pme_gather_pending(s);
+    return MDX_OK;
 }
 
 extern "C" int mdx_compute_forces(mdx_system *s, unsigned terms)
@@ -935,14 +909,11 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
         else if ((rc = mdx_launch_prepare(s, !forked_early))) return rc;
         prepared = false;
         // the nonbonded kernel is the critical path: enqueue it first, the side streams fill in
-        const bool spread_main = s->spread_on_main != 0 && phase == 0;
-        if (spread_main) if ((rc = mdx_launch_pme_spread(s, s->stream, true))) return rc;
         if ((rc = mdx_launch_nonbonded(s, need_vir, MDX_F_NONBONDED | (s->have_pme ? MDX_F_EXCL : 0)))) return rc;
         if (phase == 0) {
-            if ((rc = mdx_launch_pme(s, need_vir, spread_main))) return rc;
-            if ((s->dbg & 1024) && !need_vir) if ((rc = mdx_launch_pme(s, need_vir, false))) return rc;         // timing experiment: the (idempotent) PME chain twice
+            if ((rc = mdx_launch_pme(s, need_vir, false))) return rc;
         } else if (s->have_pme) {
-            if ((rc = mdx_launch_pme_spread(s, s->st_pme, false))) return rc;
+            if ((rc = mdx_launch_pme_spread(s, s->st_pme))) return rc;
             MDX_CHECK(s, hipEventRecord(s->ev_spread, s->st_pme));
         }
         if ((rc = mdx_launch_bonded(s, need_vir, MDX_F_BONDED | MDX_F_POSRES))) return rc;
@@ -964,31 +935,7 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
         if (phase == 1) return MDX_OK;
     }
     if (phase == 2) if ((rc = mdx_launch_pme(s, need_vir && s->dd_mesh_energy, true))) return rc;
-    if (phase == 0 && s->rotate_streams == 2 && s->have_pme && !s->one_stream && !s->gather_on_main && !s->spread_on_main && !s->bond_on_main) {
-        // The update goes behind the bonded kernels on their stream, which idles from a few microseconds into the step:
-        // its two waits (PME chain, nonbonded kernel) then stand at the head of an idle queue and are taken as their
-        // signals fire, instead of one after the other once the nonbonded kernel has retired from the main queue.
-        // That stream is the main stream of the next step (the nonbonded kernel follows the update in queue order),
-        // and this one takes the next step's bonded kernels.
-        if (!s->pme_signalled) MDX_CHECK(s, hipEventRecord(s->ev_pme, s->st_pme));
-        s->pme_signalled = false;
-        if (!s->nb_done_event) { MDX_CHECK(s, hipEventRecord(s->ev_nbdone, s->stream)); s->nb_done_event = s->ev_nbdone; }
-        MDX_CHECK(s, hipStreamWaitEvent(s->st_bond, s->ev_pme, 0));
-        MDX_CHECK(s, hipStreamWaitEvent(s->st_bond, s->nb_done_event, 0));
-        s->nb_done_event = nullptr;
-        std::swap(s->stream, s->st_bond);
-    } else if (phase == 0 && s->rotate_streams == 1 && s->have_pme && !s->gather_on_main && !s->spread_on_main) {
-        // The PME chain ends about when the nonbonded kernel does. A stream that waits for an event of another one
-        // resumes several microseconds after it fires; the update is therefore enqueued behind the gather on the
-        // PME stream, which waits for the two other streams (mostly finished by then) and becomes the main stream
-        // of the next step, while this one takes the next PME chain.
-        MDX_CHECK(s, hipEventRecord(s->ev_nbdone, s->stream));
-        MDX_CHECK(s, hipEventRecord(s->ev_bond, s->st_bond));
-        MDX_CHECK(s, hipStreamWaitEvent(s->st_pme, s->ev_nbdone, 0));
-        MDX_CHECK(s, hipStreamWaitEvent(s->st_pme, s->ev_bond, 0));
-        s->pme_signalled = false;
-        std::swap(s->stream, s->st_pme);
-    } else if ((rc = mdx_join(s))) return rc;
+    if ((rc = mdx_join(s))) return rc;
     // The PME and bonded kernels of the next step read only the new positions (the spread goes through the
     // sort permutation): when that step neither rebuilds the list nor accumulates energies they are
     // released here, ahead of the thermostat kernels and the coordinate sort, instead of by the prepare kernel.
@@ -997,10 +944,10 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
         const long long nx = step + 1;
         const bool vir_next = (s->nstcalcenergy > 0 && nx % s->nstcalcenergy == 0) || (s->pcoupl != 0 && nx % s->nstpcouple == 0);
         const bool search_next = s->steps_since_search + 1 >= s->nstlist;
-        const bool fork_now = phase == 0 && more && !vir_next && !search_next && !do_pc && s->early_fork;
+        const bool fork_now = phase == 0 && more && !vir_next && !search_next && !do_pc;
         // Steps that accumulate no virial take leap-frog and constraints in one launch, which (when another step of this
         // call follows on the same pair list and the cell stays as it is) also writes that step's sorted coordinates.
-        const bool fused = phase == 0 && !need_vir && !s->dd_on && s->fused_update && s->rotate_streams != 1 && mdx_fused_plan(s) == 1;
+        const bool fused = phase == 0 && !need_vir && !s->dd_on && s->fused_update && mdx_fused_plan(s) == 1;
         if (fused) {
             prepared = more && !search_next;
             if ((rc = mdx_launch_update_fused(s, tc_apply, s->pcoupl == 2, prepared, fork_now && prepared))) return rc;
@@ -1019,20 +966,7 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
         if ((rc = mdx_launch_finish_energy(s, do_ener ? next_energy_frame(s) : nullptr, do_pc && !s->dd_on))) return rc;
         if (do_ener) frame_steps(s).push_back(step);
     }
-    const bool comm_now = s->nstcomm > 0 && ((step + 1) % s->nstcomm == 0);
-    if (s->ntc > 0 && ((step + 1) % s->nsttcouple == 0) && phase == 0 && !need_vir && !comm_now && !s->dd_on && !s->one_stream &&
-        s->tc_on_side && more) {
-        // The thermostat's kinetic energy and the factor for the coming steps are needed by the next update only: they run
-        // on the bonded stream beside the next step's nonbonded kernel instead of in front of it (22 us of main-stream time
-        // every nsttcouple steps). The velocities they read are final once the update has completed; nothing on the main
-        // stream changes them before the next update (centre-of-mass removal and pressure coupling steps keep the old place).
-        if (!forked_early) {
-            MDX_CHECK(s, hipEventRecord(s->ev_tc, s->stream));
-            MDX_CHECK(s, hipStreamWaitEvent(s->st_bond, s->ev_tc, 0));
-        }
-        if ((rc = mdx_launch_ke(s, false, false, s->st_bond, true))) return rc;
-        if ((rc = mdx_launch_tcouple(s, s->st_bond, true))) return rc;
-    } else if (s->ntc > 0 && ((step + 1) % s->nsttcouple == 0) && !need_vir && !s->dd_on) {
+    if (s->ntc > 0 && ((step + 1) % s->nsttcouple == 0) && !need_vir && !s->dd_on) {
         // the thermostat's own accumulator, which the kernel that draws the factor leaves zeroed: no clearing launch
         if ((rc = mdx_launch_ke(s, false, false, nullptr, true))) return rc;
         if ((rc = mdx_launch_tcouple(s, nullptr, true))) return rc;
@@ -1124,10 +1058,7 @@ extern "C" int mdx_debug_time_stage(mdx_system *s, int stage, int iters, double 
     if (stage == 3) st = s->st_bond;
     hipEvent_t a, b;
     MDX_CHECK(s, hipEventCreate(&a)); MDX_CHECK(s, hipEventCreate(&b));
-    const int saved = s->dbg, saved_gather = s->gather_on_main;
-    s->gather_on_main = 0;          // the whole chain on its own stream while it is timed
-    if (stage == 6) s->dbg |= 256;
-    if (stage == 7) s->dbg |= 2048;
+    s->pme_part = stage == 6 ? 1 : (stage == 7 ? 2 : 0);
     auto run = [&]() -> int {
         switch (stage) {
         case 1: return mdx_search(s);
@@ -1150,7 +1081,7 @@ extern "C" int mdx_debug_time_stage(mdx_system *s, int stage, int iters, double 
     float ms = 0.0f;
     MDX_CHECK(s, hipEventElapsedTime(&ms, a, b));
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-    s->dbg = saved; s->gather_on_main = saved_gather;
+    s->pme_part = 0;
     s->f_dirty = true;
     MDX_CHECK(s, hipDeviceSynchronize());
     if (avg_ms) *avg_ms = ms / (iters > 0 ? iters : 1);

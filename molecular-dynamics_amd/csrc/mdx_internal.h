@@ -124,21 +124,14 @@ struct mdx_system {
     int dbg = 0;                       // diagnostic ablation bits (mdx_debug_set key 2)
     int nb_dyn = 1;                    // nonbonded kernel: rounds' worth of cheap units scheduled dynamically (mdx_debug_set key 3)
     int nb_dyn_split = 0;              // ... in 2^nb_dyn_split parts per unit (mdx_debug_set key 4)
-    int rotate_streams = 0;            // 1: the update follows the PME chain on its stream, which becomes the main stream of the next step; 2: it follows the bonded kernels on theirs (mdx_debug_set key 9)
-    hipEvent_t nb_done_event = nullptr; // completion signal of the last nonbonded launch (rotate_streams == 2), null: none attached
-    int gather_on_main = 0;            // PME gather behind the nonbonded kernel on the main stream: measured slower, the nonbonded kernel ends last (mdx_debug_set key 8)
-    const float *gather_pending = nullptr;
-    int spread_on_main = 0;            // charge spreading on the main stream ahead of the nonbonded kernel: measured slower (mdx_debug_set key 7)
-    int bond_on_main = 0;              // bonded and pull kernels behind the nonbonded kernel on the main stream (mdx_debug_set key 6)
-    int early_fork = 1;                // release the side streams of a plain step right after the previous update (mdx_debug_set key 5)
+    int pme_part = 0;                  // stage timing: 1 only the spreading, 2 only the gather of the PME chain
     long long *nb_wave_t = nullptr;    // diagnostic per-wave clock buffer (mdx_debug_wave_times)
-    int nb_variant = 33;               // nonbonded launch shape: 10 * waves/SIMD of the energy kernel + waves/SIMD of the force kernel
     bool one_stream = false;           // st_pme and st_bond are the main stream (no cross-stream waits at all)
     hipStream_t own_streams[3] = { nullptr, nullptr, nullptr };   // the three streams created for the handle (destroyed with it)
     hipStream_t stream = nullptr;      // main stream: search, nonbonded, update
     hipStream_t st_pme = nullptr;      // PME chain (spread, FFTs, solve, gather) overlaps the nonbonded kernel
     hipStream_t st_bond = nullptr;     // bonded, restraint, exclusion and pull kernels
-    hipEvent_t ev_fork = nullptr, ev_pme = nullptr, ev_bond = nullptr, ev_spread = nullptr, ev_nbdone = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_pme = nullptr, ev_bond = nullptr, ev_spread = nullptr;
     float *f_pme = nullptr;            // 3N mesh forces (plain stores, so no race with the atomics on f)
     std::string err;
     int n = 0;                    // atoms
@@ -184,9 +177,7 @@ struct mdx_system {
     // nonbonded parameters
     float rc = 1.0f, rlist = 1.1f, beta = 3.12341f;
     float4 *htab = nullptr;       // ... with h(w) = erf(z)/z beside g, for the energy kernel
-    float2 *gtab = nullptr;       // MDX_GTAB_N entries of beta^3 g (Ewald correction of the force) on a uniform r^2 grid up to rc^2
-    float4 *nut_tab = nullptr;    // force table on the bits of r^2 (nonbonded.hip, k_nonbonded_f3tn): nut_n intervals from the bit pattern nut_lo
-    int nut_n = 0; unsigned nut_lo = 0; bool nut_attr_set = false;
+    float2 *gtab = nullptr;       // MDX_GTAB_N entries of beta^3 g (Ewald correction of the force) on a uniform r^2 grid up to rc^2: per interval the line c0 + c1 r^2
     int nstlist = 10;
     // Dual pair list (mdx_set_pairlist_prune): the list above is built at `rlist` for `nstlist` steps; every `nstprune`
     // steps a kernel on the bonded stream keeps the tiles of it that have a pair within `rlist_inner` right now, and the
@@ -204,6 +195,7 @@ struct mdx_system {
     float *bmod[3] = {nullptr, nullptr, nullptr};
     hipfftHandle plan_r2c = 0, plan_c2r = 0;
     float2 *fftW[3] = {nullptr, nullptr, nullptr};   // twiddle tables exp(-2 pi i j / K) of the own transform
+    bool fft_yz = false;          // ... and a k_x plane fits into LDS with factors <= 10: y and z passes fused into one launch
     bool own_fft = false;         // every grid dimension splits into two factors <= 32: the own transform is used
     bool have_pme = false;
     // bonded
@@ -224,8 +216,6 @@ struct mdx_system {
     std::vector<int> h_settle; std::vector<int2> h_cij; std::vector<int> h_cstart;   // host copies of the constraint topology
     int fused_plan = 0;           // 0: not built yet, 1: usable, -1: this topology needs the separate kernels
     int fused_update = 1;         // use it on steps without virial (mdx_debug_set key 12)
-    int tc_on_side = 0;           // thermostat kernels of plain steps on the bonded stream, beside the next step: measured neutral, off (mdx_debug_set key 13)
-    hipEvent_t ev_tc = nullptr;   // "velocities of this step are final" for the bonded stream when no fork event follows the update
     int *comp_atom_start = nullptr, *comp_atoms = nullptr, *comp_local = nullptr, *free_atoms = nullptr; int nfree = 0;
     // integration / coupling
     float dt = 0.002f;
@@ -293,8 +283,7 @@ int mdx_join(mdx_system *s);
 int mdx_launch_prepare(mdx_system *s, bool fork = false);
 int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms);
 int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done = false);
-int mdx_launch_pme_spread(mdx_system *s, hipStream_t st, bool signal);
-int mdx_launch_pme_gather_pending(mdx_system *s);
+int mdx_launch_pme_spread(mdx_system *s, hipStream_t st);
 int mdx_launch_bonded(mdx_system *s, bool energy, unsigned flags);
 int mdx_launch_pull(mdx_system *s, bool log_now, bool energy);
 int mdx_launch_update(mdx_system *s, bool do_tc, bool do_pr, bool virial);

@@ -16,8 +16,6 @@
 #include <type_traits>
 #include <cstddef>
 
-typedef float v2f __attribute__((ext_vector_type(2)));      // two floats in an even-aligned register pair: operands of the packed FP32 instructions
-
 struct NbArgs {
     const DevState *d;
     const int *nwork;            // number of work units (device memory: the list builder or the pruning kernel counts them)
@@ -34,12 +32,9 @@ struct NbArgs {
     float inv_rc6;               // 1/rc^6
     int central;                 // index of the zero lattice shift
     int do_pairs, do_excl;       // evaluate listed pairs / the Ewald correction of excluded pairs
-    int dbg;                     // diagnostic ablation bits (timing experiments only)
     const float4 *htab;          // MDX_GTAB_N entries (g, step of g, h, step of h), h(w) = erf(z)/z
-    const float2 *gtab;          // MDX_GTAB_N entries (c0, c1): beta^3 g = c0 + c1 t on the k-th interval of t = r^2 MDX_GTAB_N / rc^2
+    const float2 *gtab;          // MDX_GTAB_N entries (c0, c1): beta^3 g = c0 + c1 r^2 on the k-th interval of t = r^2 MDX_GTAB_N / rc^2
     float tab_scale;             // MDX_GTAB_N / rc^2
-    const float4 *nut;           // force table on a grid uniform in the bits of r^2 (512 intervals per binade): per interval the lines of 1/r^2 and of 1/r^3 - beta^3 g
-    unsigned nut_lo, nut_last;   // bit pattern of the table's lowest r^2, index of its last interval
     int dyn_split;               // log2 of the parts a unit is cut into when handed out dynamically
     int dyn;                     // rounds' worth of units at the cheap end of the list handed out dynamically (0: static deal only)
     long long *wave_t;           // diagnostic: per wave (start clock, end clock, wall start, wall end, units, entries)
@@ -94,22 +89,26 @@ __device__ __forceinline__ float mdx_pmecorr(float w)
     return p * __builtin_amdgcn_rcpf(q);
 }
 
-// Second-generation kernel: the <= 32 list entries of a work unit are fetched with one coalesced
-// load and broadcast with v_readlane, the j-atoms of entry e+1 are requested before entry e is
-// evaluated, and the force-only variant replaces
-// exp + erfc by the rational Ewald correction above.
-// ABL bits: 1, 2 remove arithmetic (timing experiments); 4 takes the Ewald correction g from the table `gtab` in LDS;
-// 8 (energy kernel) takes g and h = erf(z)/z from a float4 table.
-// 16: the LJ parameters of the i-atoms live in LDS (`ilj`, 64 float2 per wave) instead of 16 registers.
+// The entries of a work unit (one per lane) are fetched with one coalesced load and broadcast with v_readlane, the
+// j-atoms of entry e+1 are requested before entry e is evaluated, and the force-only variant replaces exp + erfc by a
+// tabulated Ewald correction.
+// TAB: 0 analytic Ewald terms (no table: the fallback for a handle without Ewald tables and the cross-check of the
+// tabulated kernels); 1 (force kernel) the Ewald correction g from the table `gtab` in LDS; 2 (energy kernel) g and
+// h = erf(z)/z from a float4 table in LDS. With a table the LJ parameters of the i-atoms live in LDS too (`ilj`, 64
+// float2 per wave) instead of 16 registers.
 // NI: i-clusters of the super-cluster held in registers at a time; NI = 4 walks the unit's entries twice (36 registers
 // fewer, j-atoms loaded and j-forces reduced twice), so that waves of other kernels fit beside the energy kernel.
 // WGT: pairs carry the weights 1, 1/2, 0 in energies and virial (a domain of a decomposed run: pairs with copies of other
 // domains' atoms); a compile-time switch, because the handful of extra instructions per tile costs the energy kernel a
 // third of its speed (304 against 227 us) and a single-domain run never needs them.
-template <bool ENERGY, bool TIMED = false, int ABL = 0, int NI = 8, bool WGT = false, bool COUNT = true>
+// TIMED: per-wave clocks and tile counters for mdx_debug_wave_times.
+template <bool ENERGY, int TAB, int NI = 8, bool WGT = false, bool COUNT = true, bool TIMED = false>
 __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nullptr, float2 *ilj = nullptr)
 {
     MDX_STAMP(A.dw, ENERGY ? 2 : 1);
+    static_assert(TAB == 0 || TAB == (ENERGY ? 2 : 1), "force kernels take the float2 table, energy kernels the float4 table");
+    constexpr bool ILDS = TAB != 0;
+    constexpr bool XM = !ENERGY && TAB == 1;      // execution-masked plain tile (see the tile below)
     long long t_start = 0, w_start = 0; int n_units = 0, n_entries = 0, n_tested = 0, n_eval = 0;
     if (TIMED) { t_start = clock64(); w_start = wall_clock64(); }
     const int lane = threadIdx.x & 63;
@@ -122,6 +121,8 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
     const bool do_pairs = A.do_pairs != 0, do_excl = A.do_excl != 0;
     float vxx = 0.0f, vxy = 0.0f, vxz = 0.0f, vyy = 0.0f, vyz = 0.0f, vzz = 0.0f;
     const float rc2 = A.rc2, beta = A.beta;
+    float scale_v = A.tab_scale;
+    if (XM) asm volatile("v_mov_b32 %0, %1" : "=v"(scale_v) : "s"(A.tab_scale));    // (an operand from a scalar register halves the instruction's rate)
     const float beta2 = beta * beta, beta3 = beta2 * beta;
     const float nb2l2e = -beta2 * 1.4426950408889634f;
     // Work units are sorted by descending cost. The expensive ones are dealt statically in snake order
@@ -174,25 +175,20 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
 #pragma unroll 1
         for (int half = 0; half < 8 / NI; half++) {
         const int c0 = half * NI;
-        constexpr bool ILDS = (ABL & 16) != 0;
-        constexpr bool PK = (ABL & 128) != 0;       // x and y of positions and forces as register pairs (packed subtract and fma)
-        float xi[PK ? 1 : NI], yi[PK ? 1 : NI], zi[NI], qi[NI], hsi[ILDS ? 1 : NI], sei[ILDS ? 1 : NI];
-        v2f xyi[PK ? NI : 1], fixy[PK ? NI : 1];
+        float xi[NI], yi[NI], zi[NI], qi[NI], hsi[ILDS ? 1 : NI], sei[ILDS ? 1 : NI];
         float2 *myilj = ILDS ? ilj + (threadIdx.x >> 6) * 64 : nullptr;
         if (ILDS) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // the previous pass has read its values
-        float fix[PK ? 1 : NI], fiy[PK ? 1 : NI], fiz[NI];
+        float fix[NI], fiy[NI], fiz[NI];
         // (one load and one LDS store per wave: lane l brings the pair of the l-th i-atom)
         if (ILDS && lane < NI * 8) myilj[lane] = *at32(A.lj_s, (unsigned)((sci * 8 + c0) * 8 + lane));
 #pragma unroll
         for (int c = 0; c < NI; c++) {
             const int ia = (sci * 8 + c0 + c) * 8 + ti;
             const float4 p = *at32(A.xq_s, (unsigned)ia);
-            if (PK) { xyi[c] = (v2f){ p.x - S.x, p.y - S.y }; fixy[c] = (v2f){ 0.0f, 0.0f }; }
-            else { xi[c] = p.x - S.x; yi[c] = p.y - S.y; fix[c] = 0.0f; fiy[c] = 0.0f; }
-            zi[c] = p.z - S.z;
+            xi[c] = p.x - S.x; yi[c] = p.y - S.y; zi[c] = p.z - S.z;
             qi[c] = p.w * MDX_ONE_4PI_EPS0;
             if (!ILDS) { const float2 l = A.lj_s[ia]; hsi[c] = l.x; sei[c] = l.y; }
-            fiz[c] = 0.0f;
+            fix[c] = 0.0f; fiy[c] = 0.0f; fiz[c] = 0.0f;
         }
         // (LDS operations of one wave execute in order; the fence only keeps the compiler from moving the reads of
         // other lanes' values above the writes)
@@ -230,8 +226,6 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                 exh = ex >> c0;
             }
             float fjx = 0.0f, fjy = 0.0f, fjz = 0.0f;
-            v2f fjxy = (v2f){ 0.0f, 0.0f };
-            const v2f pjxy = (v2f){ pj.x, pj.y };
             bool did = false;           // wave-uniform: some tile of this entry had a pair inside the cutoff
             // One 8x8 tile: i-cluster c against the j-cluster. GENERAL tiles look at the exclusion and
             // liveness bits; the others (no mask slot, not a cluster with itself: the large majority, and
@@ -239,33 +233,56 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
             // shorter. The 1e-12 inside r2 keeps a filler atom, which sits exactly on a real one, finite.
             auto tile = [&](auto general_tag, const int c) {
                 constexpr bool GENERAL = decltype(general_tag)::value;
-                v2f dxy;
-                if (PK) dxy = xyi[c] - pjxy; else dxy = (v2f){ xi[c] - pj.x, yi[c] - pj.y };
-                const float dx = dxy.x, dy = dxy.y, dz = zi[c] - pj.z;
+                const float dx = xi[c] - pj.x, dy = yi[c] - pj.y, dz = zi[c] - pj.z;
                 const float r2 = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, 1.0e-12f)));
+                if (XM && !GENERAL) {
+                    // Plain tile of the force-only kernel, written for the vector unit's issue costs on gfx950 (measured,
+                    // tools/micro/valu_ops2.hip: add / mul / fma / and on vector registers take a SIMD ~2.3 clocks, compares,
+                    // conversions, shifts, selects and anything with a scalar-register operand ~4.4, v_rsq_f32 8.2 and a select
+                    // on vcc 23): the lanes inside the cutoff run the body under the execution mask (no select of the
+                    // force at the end), the table offset comes out of the mantissa of r^2 scale + 2^20 (one fma and one
+                    // and instead of multiply, convert, and, shift), the table holds its lines in r^2 itself, and the scale
+                    // sits in a vector register.
+                    const bool in_rc = r2 < rc2;
+                    if (TIMED) n_tested++;
+                    // the list is built with a buffer: an 8x8 tile none of whose pairs is inside the
+                    // cutoff right now costs only the distance test (wave-uniform skip)
+                    if (__builtin_amdgcn_ballot_w64(in_rc) == 0ull) return;
+                    if (TIMED) n_eval++;
+                    did = true;
+                    if (in_rc) {
+                        const float rinv = __frsqrt_rn(r2);
+                        const float rinv2 = rinv * rinv;
+                        // floor(t) * 8 for t = r^2 scale < 4096: at 2^20 a float's last bit is 1/8, so the sum's mantissa holds t in
+                        // eighths; the 1/16 taken off turns round-to-nearest into rounding down (a t within rounding of an
+                        // integer may land in the interval below, whose line meets the next one there)
+                        const float u = fmaf(r2, scale_v, 1048576.0f - 0.0625f);
+                        const float2 te = *(const float2 *)((const char *)gtab + (__float_as_uint(u) & 0x7FF8u));
+                        const float2 li = myilj[c * 8 + ti];
+                        const float sg = li.x + lj.x;
+                        const float e4 = fabsf(li.y) * fabsf(lj.y);
+                        const float s2 = sg * sg * rinv2;
+                        const float s6 = s2 * s2 * s2;
+                        const float t6 = e4 * s6;
+                        float fs = t6 * fmaf(12.0f, s6, -6.0f);
+                        const float qq = qi[c] * pj.w;
+                        fs = fmaf(qq, rinv, fs) * rinv2;
+                        const float g = fmaf(r2, te.y, te.x);
+                        fs = fmaf(-qq, g, fs);
+                        fix[c] = fmaf(dx, fs, fix[c]); fiy[c] = fmaf(dy, fs, fiy[c]); fiz[c] = fmaf(dz, fs, fiz[c]);
+                        fjx = fmaf(-dx, fs, fjx); fjy = fmaf(-dy, fs, fjy); fjz = fmaf(-dz, fs, fjz);
+                    }
+                    return;
+                }
                 bool within = r2 < rc2;
                 if (GENERAL) within = within && ((live >> c) & 1u);
-                // the list is built with a buffer: an 8x8 tile none of whose pairs is inside the
-                // cutoff right now costs only the distance test (wave-uniform skip)
                 if (TIMED) n_tested++;
                 if (__builtin_amdgcn_ballot_w64(within) == 0ull) return;
                 if (TIMED) n_eval++;
                 did = true;
                 const bool listed = GENERAL ? (((exh >> c) & 1u) != 0u) : true;   // false: excluded pair, Ewald correction only
-                // NUT: 1/r^2 and the Coulomb force factor 1/r^3 - beta^3 g both come from one table entry addressed by the
-                // leading bits of r^2 (lines in r^2 itself), so the pair needs no reciprocal square root, which costs the
-                // vector unit four issue slots
-                constexpr bool NUT = !ENERGY && (ABL & 256) != 0;
-                float rinv = 0.0f, rinv2, cnut = 0.0f;
-                if (NUT) {
-                    const unsigned k = min((__float_as_uint(r2) - A.nut_lo) >> 14, A.nut_last);
-                    const float4 te = ((const float4 *)gtab)[k];
-                    rinv2 = fmaf(te.y, r2, te.x);
-                    cnut = fmaf(te.w, r2, te.z);
-                } else {
-                    rinv = __frsqrt_rn(r2);
-                    rinv2 = rinv * rinv;
-                }
+                const float rinv = __frsqrt_rn(r2);
+                const float rinv2 = rinv * rinv;
                 float hs_c, se_c;
                 if (ILDS) { const float2 li = myilj[c * 8 + ti]; hs_c = li.x; se_c = li.y; } else { hs_c = hsi[c]; se_c = sei[c]; }
                 const float sg = hs_c + lj.x;
@@ -277,7 +294,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                 float fs = t6 * fmaf(12.0f, s6, -6.0f);
                 const float qq = qi[c] * pj.w;
                 float erfc_br = 0.0f, e_ex = 0.0f;
-                if (ENERGY && (ABL & 8)) {
+                if (ENERGY && TAB == 2) {
                     // g and h(w) = erf(z)/z from one LDS table entry: erfc(beta r)/r = 1/r - beta h, no exponential
                     const float t = r2 * A.tab_scale;
                     const float4 te = ((const float4 *)gtab)[(unsigned)t & (MDX_GTAB_N - 1)];
@@ -302,41 +319,24 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                         fs = listed ? fs : -qq * beta3 * g;
                         e_ex = -qq * beta * fmaf(g, w_, MDX_2_SQRTPI * ex2);
                     }
-                } else if (NUT) {
-                    // t6 (12 s6 - 6) / r^2 + qq (1/r^3 - beta^3 g); an excluded pair keeps -qq beta^3 g = qq (c - 1/r^3)
-                    fs *= rinv2;
-                    if (GENERAL && slot) fs = listed ? fmaf(qq, cnut, fs) : qq * (cnut - rinv2 * __builtin_sqrtf(rinv2));
-                    else fs = fmaf(qq, cnut, fs);
                 } else {
                     // (t6 (12 s6 - 6) + qq/r) / r^2 - qq beta^3 g; an excluded pair keeps only the last term
                     fs = fmaf(qq, rinv, fs) * rinv2;
                     if (GENERAL && slot) fs = listed ? fs : 0.0f;      // wave-uniform: few tiles hold an excluded pair
-                    float g;
-                    if (ABL & 4) {
-                        // g(beta^2 r^2) by linear interpolation in a table uniform in r^2 (entry: the interval's line c0 + c1 t):
-                        // the look-up runs on the LDS pipe next to the LJ arithmetic and replaces a dozen VALU instructions
-                        const float t = r2 * A.tab_scale;
-                        const float2 te = gtab[(unsigned)t & (MDX_GTAB_N - 1)];
-                        g = fmaf(t, te.y, te.x);      // the table holds beta^3 g
-                        fs = fmaf(-qq, g, fs);
+                    if (TAB == 1) {
+                        // g(beta^2 r^2) by linear interpolation in a table uniform in r^2 (entry: the interval's line c0 + c1 r^2;
+                        // the table holds beta^3 g): the look-up runs on the LDS pipe next to the LJ arithmetic and replaces a
+                        // dozen VALU instructions
+                        const float2 te = gtab[(unsigned)(r2 * A.tab_scale) & (MDX_GTAB_N - 1)];
+                        fs = fmaf(-qq, fmaf(r2, te.y, te.x), fs);
                     } else {
-                        g = (ABL & 1) ? beta2 * r2 : mdx_pmecorr(beta2 * r2);
-                        fs = fmaf(-qq * beta3, g, fs);
+                        fs = fmaf(-qq * beta3, mdx_pmecorr(beta2 * r2), fs);
                     }
                 }
                 fs = within ? fs : 0.0f;
                 const float fx = fs * dx, fy = fs * dy, fz = fs * dz;
-                if (PK) {
-                    // two packed fmas for x and y of both atoms' forces (four plain ones otherwise)
-                    const v2f fs2 = (v2f){ fs, fs };
-                    fixy[c] = __builtin_elementwise_fma(dxy, fs2, fixy[c]);
-                    fjxy = __builtin_elementwise_fma(-dxy, fs2, fjxy);
-                    fiz[c] = fmaf(dz, fs, fiz[c]);
-                    fjz = fmaf(-dz, fs, fjz);
-                } else {
-                    fix[c] += fx; fiy[c] += fy; fiz[c] += fz;
-                    fjx -= fx; fjy -= fy; fjz -= fz;
-                }
+                fix[c] += fx; fiy[c] += fy; fiz[c] += fz;
+                fjx -= fx; fjy -= fy; fjz -= fz;
                 if (ENERGY) {
                     // A pair between an atom of this domain and a copy of another domain's atom is evaluated by both
                     // owners: each takes half of its energy and virial; a pair of two copies belongs to others entirely.
@@ -385,11 +385,10 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
             asm volatile("" :: "v"(N.pj.x), "v"(N.pj.y), "v"(N.pj.z), "v"(N.pj.w), "v"(N.lj.x), "v"(N.lj.y), "v"(N.ex));
             // an entry none of whose tiles had a pair inside the cutoff has no j-force to reduce or add
             float fj3 = 0.0f;
-            if (PK) { fjx = fjxy.x; fjy = fjxy.y; }
-            if (did && !(ABL & 2)) fj3 = sum8_xyz(fjx, fjy, fjz, (ti & 1) != 0, (ti & 2) != 0);
+            if (did) fj3 = sum8_xyz(fjx, fjy, fjz, (ti & 1) != 0, (ti & 2) != 0);
             // (one 24-lane atomic per entry: pairing two entries into one 48-lane atomic costs more VALU instructions in
             // the selects than the second atomic costs now that no wait sits behind it)
-            if (did && ti < 3 && !((ABL & 64) && (A.dbg & 0x20000))) atomicAdd(at32(A.f_s, (unsigned)(3 * (cj * 8 + tj) + ti)), fj3);
+            if (did && ti < 3) atomicAdd(at32(A.f_s, (unsigned)(3 * (cj * 8 + tj) + ti)), fj3);
         };
         JSet Ja, Jb;
         fetch(Ja, 0);
@@ -403,8 +402,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
         }
 #pragma unroll
         for (int c = 0; c < NI; c++) {
-            float ax, ay, az = fiz[c];
-            if (PK) { ax = fixy[c].x; ay = fixy[c].y; } else { ax = fix[c]; ay = fiy[c]; }
+            const float ax = fix[c], ay = fiy[c], az = fiz[c];
             // (x, y, z over the eight j-lanes of an i-atom with the same keep-one-give-one exchanges as sum8_xyz: the lanes
             // with tj = 0, 1, 2 end with the sums of x, y, z)
             const bool t0 = (tj & 1) != 0, t1 = (tj & 2) != 0;
@@ -412,9 +410,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
             const float z_ = az + dpp_row_ror8(az);
             float val = (t1 ? z_ : a_) + __shfl_xor(t1 ? a_ : z_, 16, 64);
             val += __shfl_xor(val, 32, 64);
-            if (tj < 3 && !((ABL & 64) && (A.dbg & 0x40000))) {
-                atomicAdd(at32(A.f_s, (unsigned)(3 * ((sci * 8 + c0 + c) * 8 + ti) + tj)), val);
-            }
+            if (tj < 3) atomicAdd(at32(A.f_s, (unsigned)(3 * ((sci * 8 + c0 + c) * 8 + ti) + tj)), val);
         }
         }
         }
@@ -439,8 +435,10 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
         if (lane == 0) {
             // replicated accumulators (folded by the finishing kernel): one replica per wave index mod 64
             const int rep = wave_id & (MDX_NREP - 1);
-            atomicAdd(&A.dw->npairs_rep[rep][0], np64);
-            atomicAdd(&A.dw->npairs_rep[rep][1], nl64);
+            if (COUNT) {
+                atomicAdd(&A.dw->npairs_rep[rep][0], np64);
+                atomicAdd(&A.dw->npairs_rep[rep][1], nl64);
+            }
             atomicAdd(&A.dw->ener_rep[rep][MDX_E_LJ], (double)elj);
             atomicAdd(&A.dw->ener_rep[rep][MDX_E_COUL_SR], (double)ecoul);
             atomicAdd(&A.dw->ener_rep[rep][MDX_E_COUL_EXCL], (double)eexcl);
@@ -452,151 +450,56 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
     }
 }
 
-// Force-only steps: 4 waves per SIMD (<= 128 VGPRs). Energy/virial steps carry the extra
-// accumulators and the erfc evaluation: 3 waves per SIMD (<= 168 VGPRs) instead of spilling.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_f(NbArgs A) { nb_body<false>(A); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_ev(NbArgs A) { nb_body<true>(A); }
-// Variant that leaves a quarter of each SIMD's wave slots and registers to the kernels of the
-// PME and bonded streams (selected with mdx_debug_set key 1 = 3).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3(NbArgs A) { nb_body<false>(A); }
-// Force-only kernel with the Ewald correction tabulated in LDS. One workgroup of 12 waves per CU (3 waves per
-// SIMD) so that a CU holds the 32 KB table once and the LDS left over serves the co-running PME kernels.
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3t(NbArgs A)
-{
-    __shared__ float4 tab4[MDX_GTAB_N / 2];
-    const float4 *src = (const float4 *)A.gtab;
-    for (int k = threadIdx.x; k < MDX_GTAB_N / 2; k += 768) tab4[k] = src[k];
-    __syncthreads();
-    nb_body<false, false, 4>(A, (const float2 *)tab4);
-}
-// The same with the i-atoms' LJ parameters in LDS: 16 registers fewer, so that three such waves leave a SIMD room for
-// three waves of the co-running PME and bonded kernels instead of two.
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_f3tl(NbArgs A)
+// All kernels keep three waves per SIMD (one 12-wave workgroup per CU with a table, three 4-wave workgroups without), so
+// that the kernels of the PME and bonded streams find wave slots, registers and LDS beside them.
+//
+// Force-only kernel of the step loop: the Ewald correction from a 32 KB table in LDS, the LJ parameters of the i-atoms in
+// LDS (128 registers: three such waves leave a SIMD room for three waves of the co-running PME and bonded kernels).
+template <bool TIMED>
+__device__ __forceinline__ void nb_force_tab(const NbArgs &A)
 {
     __shared__ float4 tab4[MDX_GTAB_N / 2];
     __shared__ float2 ilj[12 * 64];
     const float4 *src = (const float4 *)A.gtab;
     for (int k = threadIdx.x; k < MDX_GTAB_N / 2; k += 768) tab4[k] = src[k];
     __syncthreads();
-    nb_body<false, false, 4 | 16>(A, (const float2 *)tab4, ilj);
+    nb_body<false, 1, 8, false, true, TIMED>(A, (const float2 *)tab4, ilj);
 }
-// The same with x and y of the positions and forces in register pairs (packed FP32 subtract and fma).
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_f3tlp(NbArgs A)
-{
-    __shared__ float4 tab4[MDX_GTAB_N / 2];
-    __shared__ float2 ilj[12 * 64];
-    const float4 *src = (const float4 *)A.gtab;
-    for (int k = threadIdx.x; k < MDX_GTAB_N / 2; k += 768) tab4[k] = src[k];
-    __syncthreads();
-    nb_body<false, false, 4 | 16 | 128>(A, (const float2 *)tab4, ilj);
-}
-// The same with the force table on the bits of r^2 (no reciprocal square root per pair); the table's size follows the cutoff.
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_f3tn(NbArgs A)
-{
-    extern __shared__ float4 dyn4[];
-    float4 *tab4 = dyn4;
-    float2 *ilj = (float2 *)(dyn4 + A.nut_last + 1);
-    for (unsigned k = threadIdx.x; k <= A.nut_last; k += 768) tab4[k] = A.nut[k];
-    __syncthreads();
-    nb_body<false, false, 16 | 256>(A, (const float2 *)tab4, ilj);
-}
-// The same with the run-time switches that leave out the force atomics (timing experiments: mdx_debug_set key 2, bits
-// 0x20000 and 0x40000); the production kernel does not carry their tests.
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_f3tl_abl(NbArgs A)
-{
-    __shared__ float4 tab4[MDX_GTAB_N / 2];
-    __shared__ float2 ilj[12 * 64];
-    const float4 *src = (const float4 *)A.gtab;
-    for (int k = threadIdx.x; k < MDX_GTAB_N / 2; k += 768) tab4[k] = src[k];
-    __syncthreads();
-    nb_body<false, false, 4 | 16 | 64>(A, (const float2 *)tab4, ilj);
-}
-// Four i-clusters at a time (two passes over the unit's entries) at four waves per SIMD: a quarter fewer registers per
-// wave, a third more waves to cover the LDS and memory latencies.
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_f4tl4(NbArgs A)
-{
-    __shared__ float4 tab4[MDX_GTAB_N / 2];
-    __shared__ float2 ilj[16 * 64];
-    const float4 *src = (const float4 *)A.gtab;
-    for (int k = threadIdx.x; k < MDX_GTAB_N / 2; k += 1024) tab4[k] = src[k];
-    __syncthreads();
-    nb_body<false, false, 4 | 16, 4>(A, (const float2 *)tab4, ilj);
-}
-// The same at 128 registers (a few spills): leaves half a SIMD's register file to co-running kernels.
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_f3t128(NbArgs A)
-{
-    __shared__ float4 tab4[MDX_GTAB_N / 2];
-    const float4 *src = (const float4 *)A.gtab;
-    for (int k = threadIdx.x; k < MDX_GTAB_N / 2; k += 768) tab4[k] = src[k];
-    __syncthreads();
-    nb_body<false, false, 4>(A, (const float2 *)tab4);
-}
-// Energy/virial kernel with g and h tabulated (64 KB per CU): no exponential, no erfc polynomial.
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_evt(NbArgs A)
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_f(NbArgs A) { nb_force_tab<false>(A); }
+// ... with per-wave clocks and tile counters (mdx_debug_wave_times)
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f_timed(NbArgs A) { nb_force_tab<true>(A); }
+// Energy/virial kernel with g and h tabulated (64 KB per CU): no exponential, no erfc polynomial. NI = 4 fits beside the
+// kernels of the PME and bonded streams; COUNT adds the pair statistics (mdx_compute_forces, and steps that ask for them);
+// WGT the pair weights of a decomposed run.
+template <int NI, bool WGT, bool COUNT>
+__device__ __forceinline__ void nb_energy_tab(const NbArgs &A)
 {
     __shared__ float4 tab4[MDX_GTAB_N];
     __shared__ float2 ilj[12 * 64];
     const float4 *src = (const float4 *)A.htab;
     for (int k = threadIdx.x; k < MDX_GTAB_N; k += 768) tab4[k] = src[k];
     __syncthreads();
-    nb_body<true, false, 8 | 16>(A, (const float2 *)tab4, ilj);
+    nb_body<true, 2, NI, WGT, COUNT>(A, (const float2 *)tab4, ilj);
 }
-// The same holding four i-clusters at a time: fits beside the kernels of the PME and bonded streams.
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_evt4(NbArgs A)
-{
-    __shared__ float4 tab4[MDX_GTAB_N];
-    __shared__ float2 ilj[12 * 64];
-    const float4 *src = (const float4 *)A.htab;
-    for (int k = threadIdx.x; k < MDX_GTAB_N; k += 768) tab4[k] = src[k];
-    __syncthreads();
-    nb_body<true, false, 8 | 16, 4>(A, (const float2 *)tab4, ilj);
-}
-// The same without the pair statistics (the energy steps of mdx_step: only mdx_compute_forces and runs that ask for
-// them with mdx_debug_set key 11 count the pairs inside the cutoff).
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_evt4n(NbArgs A)
-{
-    __shared__ float4 tab4[MDX_GTAB_N];
-    __shared__ float2 ilj[12 * 64];
-    const float4 *src = (const float4 *)A.htab;
-    for (int k = threadIdx.x; k < MDX_GTAB_N; k += 768) tab4[k] = src[k];
-    __syncthreads();
-    nb_body<true, false, 8 | 16, 4, false, false>(A, (const float2 *)tab4, ilj);
-}
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_evtn(NbArgs A)
-{
-    __shared__ float4 tab4[MDX_GTAB_N];
-    __shared__ float2 ilj[12 * 64];
-    const float4 *src = (const float4 *)A.htab;
-    for (int k = threadIdx.x; k < MDX_GTAB_N; k += 768) tab4[k] = src[k];
-    __syncthreads();
-    nb_body<true, false, 8 | 16, 8, false, false>(A, (const float2 *)tab4, ilj);
-}
-// The same with pair weights, for the domains of a decomposed run.
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_evt4w(NbArgs A)
-{
-    __shared__ float4 tab4[MDX_GTAB_N];
-    __shared__ float2 ilj[12 * 64];
-    const float4 *src = (const float4 *)A.htab;
-    for (int k = threadIdx.x; k < MDX_GTAB_N; k += 768) tab4[k] = src[k];
-    __syncthreads();
-    nb_body<true, false, 8 | 16, 4, true>(A, (const float2 *)tab4, ilj);
-}
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_evw(NbArgs A) { nb_body<true, false, 0, 8, true>(A); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3_abl1(NbArgs A) { nb_body<false, false, 1>(A); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3_abl2(NbArgs A) { nb_body<false, false, 2>(A); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f3_timed(NbArgs A) { nb_body<false, true>(A); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_nonbonded_f2(NbArgs A) { nb_body<false>(A); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_nonbonded_ev2(NbArgs A) { nb_body<true>(A); }
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_ev(NbArgs A) { nb_energy_tab<4, false, false>(A); }
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_ev_count(NbArgs A) { nb_energy_tab<4, false, true>(A); }
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_ev_dd(NbArgs A) { nb_energy_tab<4, true, true>(A); }
+// (one pass over the entries with all eight i-clusters: faster alone, slower inside the step; mdx_debug_set key 2 bit 0x1000000)
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_ev8(NbArgs A) { nb_energy_tab<8, false, false>(A); }
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_ev8_count(NbArgs A) { nb_energy_tab<8, false, true>(A); }
+// Analytic kernels (rational Ewald correction, exp + erfc polynomial in the energy kernel): what a handle without Ewald
+// tables runs, and the cross-check of the tabulated kernels (mdx_debug_set key 2 bit 0x400000).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f_analytic(NbArgs A) { nb_body<false, 0>(A); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_ev_analytic(NbArgs A) { nb_body<true, 0>(A); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_ev_analytic_dd(NbArgs A) { nb_body<true, 0, 8, true>(A); }
 
 int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
 {
     NbArgs A;
     A.central = s->central_shift;
-    A.dbg = s->dbg;
     A.wave_t = s->nb_wave_t;
     A.dyn = s->nb_dyn; A.dyn_split = s->nb_dyn_split;
     A.htab = s->htab; A.gtab = s->gtab; A.tab_scale = (float)MDX_GTAB_N / (s->rc * s->rc);
-    A.nut = s->nut_tab; A.nut_lo = s->nut_lo; A.nut_last = s->nut_n > 0 ? (unsigned)s->nut_n - 1u : 0u;
     A.do_pairs = (terms & MDX_F_NONBONDED) ? 1 : 0;
     A.do_excl = ((terms & MDX_F_EXCL) && s->beta > 0.0f) ? 1 : 0;
     if (!A.do_pairs && !A.do_excl) return MDX_OK;
@@ -612,13 +515,7 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
     A.rc2 = s->rc * s->rc; A.beta = s->beta;
     A.c_rf_shift = (float)(erfc((double)s->beta * s->rc) / s->rc);
     A.inv_rc6 = 1.0f / (A.rc2 * A.rc2 * A.rc2);
-    // grid-stride over work units: the unit count lives in device memory, so the grid is fixed
-    // (4 blocks of 4 waves per CU) and every wave exits once the list is exhausted
-    // resident waves only: `wv` blocks of 4 waves per CU. nb_variant = 10 * (energy-kernel waves) + force-kernel waves
-    int wv = energy ? s->nb_variant / 10 : s->nb_variant % 10;
-    if (wv < 2 || wv > 4 || (energy && wv == 4)) wv = 3;
-    const int nblk = 256 * wv;
-    // kernel timing samples every 8th launch: the start and stop events ride on the kernel's own dispatch
+    // kernel timing samples launches of the step loop: the start and stop events ride on the kernel's own dispatch
     // packet, so they read the kernel's begin and end time stamps (no marker packets, no launch gap inside)
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     // (force-only launches only, at a stride that does not lock onto the 10- and 20-step cadences of energy and search steps)
@@ -639,33 +536,19 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
             s->ev_nb.push_back(std::make_pair(k, k + 1));
         }
     }
-    void (*kern)(NbArgs) = k_nonbonded_f;
-    dim3 grid(nblk), block(256);
-    if (energy && wv == 2 && !s->dd_on) kern = k_nonbonded_ev2;
-    else if (energy && wv == 3 && s->htab && !(s->dbg & 0x400000)) { kern = s->dd_on ? k_nonbonded_evt4w : ((s->dbg & 0x1000000) ? (s->count_pairs ? k_nonbonded_evt : k_nonbonded_evtn) : (s->count_pairs ? k_nonbonded_evt4 : k_nonbonded_evt4n)); grid = dim3(256); block = dim3(768); }
-    else if (energy) kern = s->dd_on ? k_nonbonded_evw : k_nonbonded_ev;
-    else if (wv == 2) kern = k_nonbonded_f2;
-    else if (wv == 3) {
-        if (s->nb_wave_t) kern = k_nonbonded_f3_timed;
-        else if (s->dbg & 0x100000) kern = k_nonbonded_f3_abl1;
-        else if (s->dbg & 0x200000) kern = k_nonbonded_f3_abl2;
-        else if ((s->dbg & 0x400000) || !s->gtab) kern = k_nonbonded_f3;
-        else { kern = (s->dbg & 0x800000) ? k_nonbonded_f3t128 : ((s->dbg & 0x4000000) ? k_nonbonded_f3t : ((s->dbg & 0x60000) ? k_nonbonded_f3tl_abl : ((s->dbg & 0x20000000) ? k_nonbonded_f3tlp : k_nonbonded_f3tl))); grid = dim3(256); block = dim3(768); }
-    } else if (wv == 4 && s->gtab && !(s->dbg & 0x400000)) { kern = k_nonbonded_f4tl4; grid = dim3(256); block = dim3(1024); }
-    // (rotate_streams == 2: the update waits for this launch on another stream; the kernel's own completion signal
-    // serves, a marker recorded behind it would fire microseconds later)
-    s->nb_done_event = nullptr;
-    if (s->rotate_streams == 2) { if (!ev_b) ev_b = s->ev_nbdone; s->nb_done_event = ev_b; }
-    size_t dyn_lds = 0;
-    if (kern == k_nonbonded_f3tl && (s->dbg & 0x10000000) && s->nut_tab) {
-        kern = k_nonbonded_f3tn;
-        dyn_lds = sizeof(float4) * (size_t)s->nut_n + sizeof(float2) * 12 * 64;
-        if (dyn_lds > 64 * 1024 && !s->nut_attr_set) {
-            MDX_CHECK(s, hipFuncSetAttribute((const void *)k_nonbonded_f3tn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
-            s->nut_attr_set = true;
-        }
-    }
-    hipExtLaunchKernelGGL(kern, grid, block, dyn_lds, s->stream, ev_a, ev_b, 0, A);
+    // The grid holds the resident waves only (the unit count lives in device memory, every wave walks the list until it
+    // is exhausted): one 12-wave workgroup per CU for the kernels with a table, three 4-wave workgroups per CU without.
+    const bool tables = s->gtab && s->htab && !(s->dbg & 0x400000);
+    void (*kern)(NbArgs);
+    dim3 grid(256), block(768);
+    if (!tables) {
+        kern = energy ? (s->dd_on ? k_nonbonded_ev_analytic_dd : k_nonbonded_ev_analytic) : k_nonbonded_f_analytic;
+        grid = dim3(256 * 3); block = dim3(256);
+    } else if (!energy) kern = s->nb_wave_t ? k_nonbonded_f_timed : k_nonbonded_f;
+    else if (s->dd_on) kern = k_nonbonded_ev_dd;
+    else if (s->dbg & 0x1000000) kern = s->count_pairs ? k_nonbonded_ev8_count : k_nonbonded_ev8;
+    else kern = s->count_pairs ? k_nonbonded_ev_count : k_nonbonded_ev;
+    hipExtLaunchKernelGGL(kern, grid, block, 0, s->stream, ev_a, ev_b, 0, A);
     MDX_CHECK(s, hipGetLastError());
     return MDX_OK;
 }
@@ -695,7 +578,7 @@ extern "C" int mdx_debug_time_nonbonded(mdx_system *s, int energy, int iters, do
     return rc;
 }
 
-// Diagnostic: one launch of the force-only kernel (3 waves/SIMD shape) with per-wave clocks; out holds 10 values per wave
+// Diagnostic: one launch of the force-only kernel with per-wave clocks; out holds 10 values per wave
 // (shader clock at start and end, 100 MHz wall clock at start and end, work units, list entries, HW_ID, XCC_ID, 8x8 tiles tested, tiles evaluated).
 extern "C" int mdx_debug_wave_times(mdx_system *s, long long *out, int max_waves, int *nwaves)
 {
@@ -705,11 +588,11 @@ extern "C" int mdx_debug_wave_times(mdx_system *s, long long *out, int max_waves
     long long *d = nullptr;
     MDX_CHECK(s, hipMalloc((void **)&d, sizeof(long long) * 10 * nw));
     MDX_CHECK(s, hipMemsetAsync(d, 0, sizeof(long long) * 10 * nw, s->stream));
-    const int keep_var = s->nb_variant; const bool keep = s->time_nb;
-    s->nb_variant = 33; s->time_nb = false; s->nb_wave_t = d;
+    const bool keep = s->time_nb;
+    s->time_nb = false; s->nb_wave_t = d;
     (void)hipMemsetAsync((char *)s->d + offsetof(DevState, nb_head), 0, sizeof(int) * 8 * 32, s->stream);
     int rc = mdx_launch_nonbonded(s, false, MDX_F_NONBONDED | MDX_F_EXCL);
-    s->nb_wave_t = nullptr; s->nb_variant = keep_var; s->time_nb = keep;
+    s->nb_wave_t = nullptr; s->time_nb = keep;
     if (rc == MDX_OK && hipMemcpyAsync(out, d, sizeof(long long) * 10 * nw, hipMemcpyDeviceToHost, s->stream) != hipSuccess) rc = MDX_ERR_HIP;
     if (hipStreamSynchronize(s->stream) != hipSuccess) rc = MDX_ERR_HIP;
     (void)hipFree(d);
@@ -734,17 +617,10 @@ extern "C" int mdx_debug_stamps(mdx_system *s, int reset, long long *out48)
 
 extern "C" int mdx_debug_set(mdx_system *s, int key, int value)
 {
-    if (key == 1) { s->nb_variant = value; return MDX_OK; }
     if (key == 2) { s->dbg = value; return MDX_OK; }
     if (key == 3) { s->nb_dyn = value; return MDX_OK; }
-    if (key == 8) { s->gather_on_main = value; return MDX_OK; }
-    if (key == 9) { s->rotate_streams = value; return MDX_OK; }
-    if (key == 7) { s->spread_on_main = value; return MDX_OK; }
-    if (key == 6) { s->bond_on_main = value; return MDX_OK; }
-    if (key == 5) { s->early_fork = value; return MDX_OK; }
     if (key == 4 && value >= 0 && value <= 3) { s->nb_dyn_split = value; return MDX_OK; }
     if (key == 11) { s->count_pairs_steps = s->count_pairs = value != 0; return MDX_OK; }     // energy steps of mdx_step count the pairs inside the cutoff
-    if (key == 13) { s->tc_on_side = value != 0; return MDX_OK; }       // thermostat kernels of plain steps on the bonded stream
     if (key == 12) { s->fused_update = value != 0; return MDX_OK; }     // leap-frog + constraints (+ next sorted coordinates) in one launch
     if (key == 14) { s->nb_chunk = value; s->steps_since_search = 1 << 30; return MDX_OK; }   // list entries per work unit (the next search applies it)
     if (key == 10) {      // streams per handle: 1 (every kernel in one stream's order) or 3

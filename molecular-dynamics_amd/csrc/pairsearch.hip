@@ -288,7 +288,6 @@ struct ListArgs {
     unsigned char *exclmask;     // 64-byte masks, MDX_EXCL_PER_WAVE slots per (super-cluster, wave)
     float rlist;
     int chunk;                   // list entries per work unit (<= 64)
-    int dbg;                     // diagnostic ablation bits (timing experiments only)
 };
 
 #define EBUF 768          // entries of one (super-cluster, shift) buffered in LDS
@@ -368,7 +367,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
     for (int s = 0; s < A.nshift; s++) {
         const float4 S = A.shiftvec[s];
         const bool central = (s == A.central);
-        if ((A.dbg & 2048) && !central) continue;
         const float3 slo = make_float3(slo4.x - S.x, slo4.y - S.y, slo4.z - S.z);
         const float3 shi = make_float3(shi4.x - S.x, shi4.y - S.y, shi4.z - S.z);
         if (shi.z + A.rlist < 0.0f || slo.z - A.rlist > cz) continue;
@@ -406,7 +404,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
                     if (central) ok = ok && (scj_l >= sci);
                     if (ok) { const float4 jl = A.sbb_lo[scj_l]; ok = bb_dist2(slo, shi, jl, A.sbb_hi[scj_l]) < rl2 && !(slo4.w != 0.0f && jl.w != 0.0f); }
                     unsigned long long m = __ballot(ok);
-                    if (A.dbg & 4096) m = 0;
                     while (m) {
                         const int b = __ffsll((long long)m) - 1;
                         m &= m - 1;
@@ -422,11 +419,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
                         const unsigned long long cm = __ballot(okc);
                         // boxes this close hold a pair within rlist almost surely: listed without the atom test
                         // (a tile listed in vain costs the nonbonded kernel one skipped tile, never correctness)
-                        const unsigned long long cs = __ballot(okc && bd2 < rbb2) & ((A.dbg & 8192) ? 0ull : ~0ull);
-                        if (!cm || (A.dbg & 1024)) continue;
+                        const unsigned long long cs = __ballot(okc && bd2 < rbb2);
+                        if (!cm) continue;
                         // j-atoms whose index has its bit in the filter over all exclusion partners of the i-atoms
-                        const unsigned long long bh = (A.dbg & 16384) ? 0ull :
-                            __ballot(ojv >= 0 && ((excl_bloom[(ojv >> 5) & 255] >> (ojv & 31)) & 1u));
+                        const unsigned long long bh = __ballot(ojv >= 0 && ((excl_bloom[(ojv >> 5) & 255] >> (ojv & 31)) & 1u));
                         xj_sh[wv][lane] = xjv;
                         origj_sh[wv][lane] = ojv;
                         __builtin_amdgcn_wave_barrier();
@@ -441,8 +437,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
                             const unsigned sure = (unsigned)((cs >> (8 * cjl)) & 0xFFull);
                             unsigned newim = sure, exb = 0xFF;
                             const unsigned test = im & ~sure;
-                            if (A.dbg & 512) newim = im;
-                            else if (test) {
+                            if (test) {
 #pragma unroll
                                 for (int ci = 0; ci < 8; ci++) {
                                     if (!(test & (1u << ci))) continue;       // wave-uniform
@@ -792,7 +787,7 @@ int mdx_search(mdx_system *s)
     A.molid_s = s->molid_s; A.bb_lo = s->bb_lo; A.bb_hi = s->bb_hi; A.sbb_lo = s->sbb_lo; A.sbb_hi = s->sbb_hi;
     A.shiftvec = s->shiftvec; A.nshift = s->nshift; A.central = s->central_shift; A.excl_start = s->excl_start;
     A.excl_list = s->excl_list; A.cj = s->cj; A.work = s->work; A.sc_nwork = s->sc_nwork;
-    A.exclmask = s->exclmask; A.rlist = s->rlist; A.dbg = s->dbg;
+    A.exclmask = s->exclmask; A.rlist = s->rlist;
     A.chunk = std::min(64, std::max(8, s->nb_chunk));
     const int nblk = s->npad / 64;
     hipLaunchKernelGGL(k_build_list, dim3(nblk), dim3(256), 0, s->stream, A);

@@ -60,233 +60,6 @@ __device__ __forceinline__ int pmod_small(int a, int K, float invK)
 
 #define MDX_SPREAD_SCALE 67108864.0f      // 2^26
 
-struct SpreadArgs {
-    int ncx, ncy;
-    const int *col_scstart;
-    const float4 *x;             // state positions (original order)
-    const int *perm, *perm_src, *shift_s;   // sorted slot -> atom (-1 filler), source atom, packed lattice shift
-    int K0, K1, K2;
-    int T0, T1;          // LDS window per grid plane (x, y)
-    int ppc;             // tile planes per workgroup
-    float delta;         // drift margin in nm used for the window origins
-    float *grid;
-    const float4 *v_home;        // domain decomposition: velocities (w = inverse mass); atoms with w == 0 are halo copies and are not spread
-};
-
-// Charge spreading with one workgroup per (pair-search column, slab of grid planes).
-// The grid is stored x-fastest: grid[(iz*K1 + iy)*K0 + ix]. In a lower-triangular box the x-run
-// touched by a compact group of atoms is contiguous for fixed (iy, iz), while the run along z is
-// not (the c vector is tilted), so windows are kept per plane: window origin (ox, oy) follows the
-// shear of the cell with the plane's height. Contributions are accumulated in LDS with ds_add_f32
-// and flushed once with row-contiguous float atomics; a contribution that falls outside its
-// window (an atom that drifted far since the last pair search) goes straight to global memory.
-__global__ __launch_bounds__(256) void k_pme_spread_col(SpreadArgs A, const DevState *__restrict__ d)
-{
-    MDX_STAMP(d, 3);
-    extern __shared__ float tile[];
-    int *ox = (int *)(tile + A.ppc * A.T1 * A.T0);
-    int *oy = ox + A.ppc;
-    const int col = blockIdx.x;
-    const int a0 = A.col_scstart[col] * 64, a1 = A.col_scstart[col + 1] * 64;
-    if (a0 == a1) return;
-    const DevBox &bx = d->box;
-    const int tp0 = blockIdx.y * A.ppc;
-    const float wx = bx.h[0] / A.ncx, wy = bx.h[4] / A.ncy;
-    const int cxi = col % A.ncx, cyi = col / A.ncx;
-    const float x_lo = cxi * wx - A.delta, x_hi = (cxi + 1) * wx + A.delta;
-    const float y_lo = cyi * wy - A.delta, y_hi = (cyi + 1) * wy + A.delta;
-    for (int p = threadIdx.x; p < A.ppc; p += blockDim.x) {
-        const int tp = tp0 + p;
-        // atoms contributing to tile plane tp have floor(u_z) in [tp-6, tp-3]
-        const float z_lo = (tp - 6) / (A.K2 * bx.inv[8]) - A.delta, z_hi = (tp - 2) / (A.K2 * bx.inv[8]) + A.delta;
-        const float ux = A.K0 * (x_lo * bx.inv[0] + fminf(y_lo * bx.inv[3], y_hi * bx.inv[3]) + fminf(z_lo * bx.inv[6], z_hi * bx.inv[6]));
-        const float uy = A.K1 * (y_lo * bx.inv[4] + fminf(z_lo * bx.inv[7], z_hi * bx.inv[7]));
-        ox[p] = (int)floorf(ux); oy[p] = (int)floorf(uy);
-    }
-    const int nt = A.ppc * A.T1 * A.T0;
-    for (int k = threadIdx.x; k < nt; k += blockDim.x) tile[k] = 0.0f;
-    __syncthreads();
-    const int nwork = (a1 - a0) * 4;
-    for (int w = threadIdx.x; w < nwork; w += blockDim.x) {
-        // position in the brick cell straight from the state: source atom of the sorted slot plus its
-        // stored lattice shift (what the prepare kernel writes for the nonbonded kernel; reading it
-        // here lets the PME stream start before that kernel has run)
-        const int gs = a0 + (w >> 2);
-        if (A.perm[gs] < 0) continue;                       // filler slot of a padded cluster
-        float4 p = A.x[A.perm_src[gs]];
-        if (p.w == 0.0f) continue;
-        if (A.v_home && A.v_home[A.perm_src[gs]].w == 0.0f) continue;
-        int sa, sb, sc;
-        unpack_shift(A.shift_s[gs], sa, sb, sc);
-        p.x += sa * bx.h[0] + sb * bx.h[3] + sc * bx.h[6];
-        p.y += sb * bx.h[4] + sc * bx.h[7];
-        p.z += sc * bx.h[8];
-        float u[3];
-        grid_coords(bx, p, A.K0, A.K1, A.K2, u);
-        const int px = (int)floorf(u[0]), py = (int)floorf(u[1]), pz = (int)floorf(u[2]);
-        const int c = w & 3;
-        const int tp = pz + c + 3;
-        if (tp < tp0 || tp >= tp0 + A.ppc) continue;
-        float wxs[4], wys[4], wzs[4], dws[4];
-        bspline4(u[0] - px, wxs, dws); bspline4(u[1] - py, wys, dws); bspline4(u[2] - pz, wzs, dws);
-        const float wzc = c == 0 ? wzs[0] : (c == 1 ? wzs[1] : (c == 2 ? wzs[2] : wzs[3]));
-        const int pl = tp - tp0;
-        const int rx0 = px - ox[pl], ry0 = py - oy[pl];
-        const float qz = p.w * wzc;
-        if (rx0 >= 0 && rx0 + 3 < A.T0 && ry0 >= 0 && ry0 + 3 < A.T1) {
-            // LDS accumulation in 32-bit fixed point (2^-26 e per count, range +-32 e per tile point):
-            // the integer LDS atomic runs several times faster than ds_add_f32 and is order-independent
-            float *t = tile + (pl * A.T1 + ry0) * A.T0 + rx0;
-            const float qzs = qz * MDX_SPREAD_SCALE;
-#pragma unroll
-            for (int b = 0; b < 4; b++)
-#pragma unroll
-                for (int a = 0; a < 4; a++) atomicAdd((int *)&t[b * A.T0 + a], __float2int_rn(qzs * wys[b] * wxs[a]));
-        } else {
-            const int gz = pmod(pz + c, A.K2);
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int gy = pmod(py + b, A.K1);
-#pragma unroll
-                for (int a = 0; a < 4; a++)
-                    atomicAdd(&A.grid[((size_t)gz * A.K1 + gy) * A.K0 + pmod(px + a, A.K0)], qz * wys[b] * wxs[a]);
-            }
-        }
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < nt; k += blockDim.x) {
-        const int vi = ((const int *)tile)[k];
-        if (vi == 0) continue;
-        const float v = (float)vi * (1.0f / MDX_SPREAD_SCALE);
-        const int rx = k % A.T0, ry = (k / A.T0) % A.T1, pl = k / (A.T0 * A.T1);
-        const int gz = pmod(tp0 + pl - 3, A.K2), gy = pmod(oy[pl] + ry, A.K1), gx = pmod(ox[pl] + rx, A.K0);
-        atomicAdd(&A.grid[((size_t)gz * A.K1 + gy) * A.K0 + gx], v);
-    }
-}
-
-// Charge spreading with one thread per atom. A workgroup takes up to four consecutive super-clusters of one
-// pair-search column (256 sorted slots: atoms that lie on top of each other in z) and accumulates them into an LDS
-// window of its own: the column's footprint in x and y, the planes those atoms can reach in z. Each thread evaluates
-// its atom's splines once and adds its 4 x 4 x 4 contributions with integer LDS atomics (fixed point, 2^-26 e); the
-// window's non-zero points are then added to the grid with float atomics. Against one workgroup per (column, slab of
-// planes) with four threads per atom this evaluates every atom once instead of twelve times (every slab's workgroup
-// walked the whole column), which is what counts beside the nonbonded kernel, where these waves get the issue slots
-// that kernel leaves over. Window origins are kept per plane as above (the cell's c vector is tilted).
-struct SpreadChunkArgs {
-    int ncx, ncy;
-    const int *col_scstart;
-    const float4 *x;
-    const int *perm, *perm_src, *shift_s;
-    const float4 *sbb_lo, *sbb_hi;      // super-cluster bounding boxes of the last search (brick coordinates)
-    int K0, K1, K2;
-    int T0, T1, PPC;                    // window size in x, y and planes
-    int sc_per_chunk;                   // super-clusters per workgroup (<= 4)
-    int abl;                            // timing experiments (MDX_SPREAD_ABL): 1 no flush atomics, 2 no LDS atomics
-    float delta;
-    float *grid;
-    const float4 *v_home;
-};
-
-__global__ __launch_bounds__(256) void k_pme_spread_chunk(SpreadChunkArgs A, const DevState *__restrict__ d)
-{
-    MDX_STAMP_ALL(d, 3);
-    extern __shared__ float tile[];
-    int *ox = (int *)(tile + A.PPC * A.T1 * A.T0);
-    int *oy = ox + A.PPC, *oxw = oy + A.PPC, *oyw = oxw + A.PPC;      // window origins per plane: as computed, and wrapped into the grid
-    const int col = blockIdx.x;
-    const int sc_first = A.col_scstart[col] + blockIdx.y * A.sc_per_chunk;
-    const int sc_end = min(A.col_scstart[col + 1], sc_first + A.sc_per_chunk);
-    if (sc_first >= sc_end) return;                 // uniform for the workgroup
-    const DevBox &bx = d->box;
-    const float wx = bx.h[0] / A.ncx, wy = bx.h[4] / A.ncy;
-    const int cxi = col % A.ncx, cyi = col / A.ncx;
-    const float x_lo = cxi * wx - A.delta, x_hi = (cxi + 1) * wx + A.delta;
-    const float y_lo = cyi * wy - A.delta, y_hi = (cyi + 1) * wy + A.delta;
-    // lowest plane the chunk's atoms can touch: floor(u_z) + 3 in tile-plane numbering (as in k_pme_spread_col)
-    const float zmin = A.sbb_lo[sc_first].z - A.delta;
-    const int tp0 = (int)floorf(A.K2 * bx.inv[8] * zmin) + 3;
-    for (int p = threadIdx.x; p < A.PPC; p += blockDim.x) {
-        const int tp = tp0 + p;
-        const float z_lo = (tp - 6) / (A.K2 * bx.inv[8]) - A.delta, z_hi = (tp - 2) / (A.K2 * bx.inv[8]) + A.delta;
-        const float ux = A.K0 * (x_lo * bx.inv[0] + fminf(y_lo * bx.inv[3], y_hi * bx.inv[3]) + fminf(z_lo * bx.inv[6], z_hi * bx.inv[6]));
-        const float uy = A.K1 * (y_lo * bx.inv[4] + fminf(z_lo * bx.inv[7], z_hi * bx.inv[7]));
-        ox[p] = (int)floorf(ux); oy[p] = (int)floorf(uy);
-        oxw[p] = pmod(ox[p], A.K0); oyw[p] = pmod(oy[p], A.K1);
-    }
-    const int nt = A.PPC * A.T1 * A.T0;
-#pragma unroll 1
-    for (int k = threadIdx.x; k < nt; k += blockDim.x) tile[k] = 0.0f;
-    __syncthreads();
-    const int gs = sc_first * 64 + threadIdx.x;
-    if (gs < sc_end * 64 && A.perm[gs] >= 0) {
-        const int src = A.perm_src[gs];
-        float4 p = A.x[src];
-        const bool skip = p.w == 0.0f || (A.v_home && A.v_home[src].w == 0.0f);
-        if (!skip) {
-            int sa, sb, sc;
-            unpack_shift(A.shift_s[gs], sa, sb, sc);
-            p.x += sa * bx.h[0] + sb * bx.h[3] + sc * bx.h[6];
-            p.y += sb * bx.h[4] + sc * bx.h[7];
-            p.z += sc * bx.h[8];
-            float u[3];
-            grid_coords(bx, p, A.K0, A.K1, A.K2, u);
-            const int px = (int)floorf(u[0]), py = (int)floorf(u[1]), pz = (int)floorf(u[2]);
-            float wxs[4], wys[4], wzs[4], dws[4];
-            bspline4(u[0] - px, wxs, dws); bspline4(u[1] - py, wys, dws); bspline4(u[2] - pz, wzs, dws);
-            const float qs = p.w * MDX_SPREAD_SCALE;
-            // (at most 40 registers, so that three of these waves fit on a SIMD beside three 128-register nonbonded waves)
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const int pl = pz + c + 3 - tp0;
-                const float wzc = (c == 0) ? wzs[0] : ((c == 1) ? wzs[1] : ((c == 2) ? wzs[2] : wzs[3]));
-                const float qz = qs * wzc;
-                const bool inpl = pl >= 0 && pl < A.PPC;
-                const int rx0 = inpl ? px - ox[pl] : -1, ry0 = inpl ? py - oy[pl] : -1;
-                if (rx0 >= 0 && rx0 + 3 < A.T0 && ry0 >= 0 && ry0 + 3 < A.T1) {
-                    int *t = (int *)tile + (pl * A.T1 + ry0) * A.T0 + rx0;
-#pragma unroll
-                    for (int b = 0; b < 4; b++) {
-                        const float qzy = qz * wys[b];
-#pragma unroll
-                        for (int a = 0; a < 4; a++) if (!(A.abl & 2)) atomicAdd(&t[b * A.T0 + a], __float2int_rn(qzy * wxs[a]));
-                    }
-                } else {
-                    // outside the window (an atom that drifted far, or a chunk taller than the window): straight to the grid
-                    const int gz = pmod(pz + c, A.K2);
-                    const float qzf = p.w * wzc;
-#pragma unroll 1
-                    for (int ba = 0; ba < 16; ba++) {       // rare path: rolled, registers matter more than speed here
-                        const int b = ba >> 2, a = ba & 3;
-                        const float wyb = (b == 0) ? wys[0] : ((b == 1) ? wys[1] : ((b == 2) ? wys[2] : wys[3]));
-                        const float wxa = (a == 0) ? wxs[0] : ((a == 1) ? wxs[1] : ((a == 2) ? wxs[2] : wxs[3]));
-                        atomicAdd(&A.grid[((size_t)gz * A.K1 + pmod(py + b, A.K1)) * A.K0 + pmod(px + a, A.K0)], qzf * wyb * wxa);
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // Flush of the non-zero window points. A thread keeps its (rx, ry) inside the plane window and walks the planes,
-    // so the index arithmetic of a point is a few additions (divisions only once per thread and window position).
-    const int t01 = A.T0 * A.T1;
-    const int gz0 = pmod(tp0 - 3, A.K2);
-#pragma unroll 1
-    for (int i = threadIdx.x; i < t01; i += blockDim.x) {
-        const int ry = i / A.T0, rx = i - ry * A.T0;
-        int gz = gz0;
-#pragma unroll 1
-        for (int pl = 0; pl < A.PPC; pl++) {
-            const int vi = ((const int *)tile)[pl * t01 + i];
-            if (vi != 0) {
-                int gx = oxw[pl] + rx, gy = oyw[pl] + ry;
-                gx -= gx >= A.K0 ? A.K0 : 0; gy -= gy >= A.K1 ? A.K1 : 0;
-                if (!(A.abl & 1)) atomicAdd(&A.grid[((size_t)gz * A.K1 + gy) * A.K0 + gx], (float)vi * (1.0f / MDX_SPREAD_SCALE));
-            }
-            gz++; gz -= gz >= A.K2 ? A.K2 : 0;
-        }
-    }
-}
-
 // Charge spreading over slabs of grid planes. A workgroup owns the planes [tlo, tlo + SP) (unwrapped plane numbers; the
 // flush wraps them) above a block of qx x qy neighbouring search columns: it collects the super-clusters of those
 // columns that can reach its planes, evaluates each of their atoms once (one thread per atom, a wave per super-cluster)
@@ -304,7 +77,6 @@ struct SpreadSlabArgs {
     int K0, K1, K2;
     int T0, T1, SP;                     // window size in x and y; planes per slab
     int tlo0;                           // lowest unwrapped plane of the first slab
-    int abl;                            // timing experiments (MDX_SPREAD_ABL): 1 no flush atomics, 2 no LDS atomics
     float delta;
     float *grid;
     const float4 *v_home;
@@ -390,7 +162,7 @@ __global__ __launch_bounds__(256) void k_pme_spread_slab(SpreadSlabArgs A, const
                             for (int b = 0; b < 4; b++) {
                                 const float qzy = qz * wys[b];
 #pragma unroll
-                                for (int a = 0; a < 4; a++) if (!(A.abl & 2)) atomicAdd(&t[b * A.T0 + a], __float2int_rn(qzy * wxs[a]));
+                                for (int a = 0; a < 4; a++) atomicAdd(&t[b * A.T0 + a], __float2int_rn(qzy * wxs[a]));
                             }
                         } else {
                             // outside the window (an atom that drifted far): straight to the grid
@@ -424,7 +196,7 @@ __global__ __launch_bounds__(256) void k_pme_spread_slab(SpreadSlabArgs A, const
             if (vi != 0) {
                 int gx = oxw[pl] + rx, gy = oyw[pl] + ry;
                 gx -= gx >= A.K0 ? A.K0 : 0; gy -= gy >= A.K1 ? A.K1 : 0;
-                if (!(A.abl & 1)) atomicAdd(&A.grid[((size_t)gz * A.K1 + gy) * A.K0 + gx], (float)vi * (1.0f / MDX_SPREAD_SCALE));
+                atomicAdd(&A.grid[((size_t)gz * A.K1 + gy) * A.K0 + gx], (float)vi * (1.0f / MDX_SPREAD_SCALE));
             }
             gz++; gz -= gz >= A.K2 ? A.K2 : 0;
         }
@@ -505,6 +277,7 @@ struct FftArgs {
     int K0, K1, K2, K0c;
     int N, N1, N2;
     int nl;                     // lines per workgroup
+    int tr;                     // cgrid stored as (K0/2+1, K2, K1), y fastest: every k_x plane contiguous (the fused y/z kernel's layout)
     // influence function (z pass)
     const DevState *d; DevState *dw; const float *bm0, *bm1, *bm2; float beta;
 };
@@ -638,118 +411,6 @@ __device__ __forceinline__ void dft_lines_fast(float2 *a, float2 *b, const float
     __syncthreads();
 }
 
-// The same two passes for lines laid out with strides: element n of line l at a[l * ls + n * es]. With LINE_FAST
-// consecutive threads take consecutive lines (for es > 1, where consecutive n would collide on LDS banks).
-template <bool LINE_FAST>
-__device__ __forceinline__ void dft_strided(float2 *a, float2 *b, const float2 *W, int nl, int N, int N1, int N2, bool inverse, int ls, int es)
-{
-    const float sgn = inverse ? -1.0f : 1.0f;
-    for (int idx = threadIdx.x; idx < nl * N; idx += blockDim.x) {
-        const int line = LINE_FAST ? idx % nl : idx / N, r = LINE_FAST ? idx / nl : idx - (idx / N) * N;
-        const int k1 = r / N2, n2 = r - k1 * N2;
-        const float2 *x = a + line * ls + n2 * es;
-        float re = 0.0f, im = 0.0f;
-        int j = 0; const int step = k1 * N2;
-        for (int n1 = 0; n1 < N1; n1++) {
-            const float2 w = W[j]; const float2 v = x[n1 * N2 * es];
-            const float wy = sgn * w.y;
-            re = fmaf(v.x, w.x, fmaf(-v.y, wy, re));
-            im = fmaf(v.x, wy, fmaf(v.y, w.x, im));
-            j += step; if (j >= N) j -= N;
-        }
-        const float2 t = W[n2 * k1]; const float ty = sgn * t.y;
-        b[line * ls + r * es] = make_float2(re * t.x - im * ty, re * ty + im * t.x);
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < nl * N; idx += blockDim.x) {
-        const int line = LINE_FAST ? idx % nl : idx / N, r = LINE_FAST ? idx / nl : idx - (idx / N) * N;
-        const int k1 = r / N2, k2 = r - k1 * N2;
-        const float2 *x = b + line * ls + k1 * N2 * es;
-        float re = 0.0f, im = 0.0f;
-        int j = 0; const int step = k2 * N1;
-        for (int n2 = 0; n2 < N2; n2++) {
-            const float2 w = W[j]; const float2 v = x[n2 * es];
-            const float wy = sgn * w.y;
-            re = fmaf(v.x, w.x, fmaf(-v.y, wy, re));
-            im = fmaf(v.x, wy, fmaf(v.y, w.x, im));
-            j += step; if (j >= N) j -= N;
-        }
-        a[line * ls + (k1 + N1 * k2) * es] = make_float2(re, im);
-    }
-    __syncthreads();
-}
-
-// x and y passes of one grid plane in one workgroup (planes of up to ~100 KB of LDS): forward reads the real plane in
-// batches of XB lines (leaving it zeroed), keeps the half-complex plane in LDS for the y pass and stores it; inverse
-// goes the other way and writes the real potential plane. Two launches and two passes through memory less per direction.
-#define MDX_FFT_XB 16
-struct Fft2Args {
-    float *grid_in; float *grid_out; float2 *cgrid;
-    const float2 *W0, *W1;
-    int K0, K1, K0c;
-    int N01, N02, N11, N12;     // factor pairs of K0 and K1
-};
-template <bool INVERSE>
-__global__ __launch_bounds__(512) void k_pme_fft2d(Fft2Args A, const DevState *d)
-{
-    MDX_STAMP(d, INVERSE ? 7 : 4);
-    extern __shared__ float2 fsm[];
-    const int K0 = A.K0, K1 = A.K1, K0c = A.K0c, ps = K0c + 1, xs = K0 + 1;
-    float2 *W0 = fsm, *W1 = W0 + K0, *P = W1 + K1, *Q = P + K1 * ps, *xa = Q + K1 * ps, *xb = xa + MDX_FFT_XB * xs;
-    for (int j = threadIdx.x; j < K0; j += blockDim.x) W0[j] = A.W0[j];
-    for (int j = threadIdx.x; j < K1; j += blockDim.x) W1[j] = A.W1[j];
-    const size_t plane = blockIdx.x;
-    float *rin = A.grid_in + plane * K1 * K0;
-    float *rout = A.grid_out + plane * K1 * K0;
-    float2 *cp = A.cgrid + plane * K1 * K0c;
-    if (!INVERSE) {
-        for (int l0 = 0; l0 < K1; l0 += MDX_FFT_XB) {
-            const int nl = min(MDX_FFT_XB, K1 - l0);
-            for (int idx = threadIdx.x; idx < nl * K0; idx += blockDim.x) {
-                const int l = idx / K0, n = idx - l * K0;
-                const float q = rin[(l0 + l) * K0 + n];
-                rin[(l0 + l) * K0 + n] = 0.0f;
-                xa[l * xs + n] = make_float2(q, 0.0f);
-            }
-            __syncthreads();
-            dft_strided<false>(xa, xb, W0, nl, K0, A.N01, A.N02, false, xs, 1);
-            for (int idx = threadIdx.x; idx < nl * K0c; idx += blockDim.x) {
-                const int l = idx / K0c, k = idx - l * K0c;
-                P[(l0 + l) * ps + k] = xa[l * xs + k];
-            }
-            __syncthreads();
-        }
-        dft_strided<true>(P, Q, W1, K0c, K1, A.N11, A.N12, false, 1, ps);
-        for (int idx = threadIdx.x; idx < K1 * K0c; idx += blockDim.x) {
-            const int y = idx / K0c, k = idx - y * K0c;
-            cp[idx] = P[y * ps + k];
-        }
-    } else {
-        for (int idx = threadIdx.x; idx < K1 * K0c; idx += blockDim.x) {
-            const int y = idx / K0c, k = idx - y * K0c;
-            P[y * ps + k] = cp[idx];
-        }
-        __syncthreads();
-        dft_strided<true>(P, Q, W1, K0c, K1, A.N11, A.N12, true, 1, ps);
-        for (int l0 = 0; l0 < K1; l0 += MDX_FFT_XB) {
-            const int nl = min(MDX_FFT_XB, K1 - l0);
-            for (int idx = threadIdx.x; idx < nl * K0c; idx += blockDim.x) {
-                const int l = idx / K0c, k = idx - l * K0c;
-                const float2 v = P[(l0 + l) * ps + k];
-                xa[l * xs + k] = v;
-                if (k > 0 && K0 - k >= K0c) xa[l * xs + K0 - k] = make_float2(v.x, -v.y);
-            }
-            __syncthreads();
-            dft_strided<false>(xa, xb, W0, nl, K0, A.N01, A.N02, true, xs, 1);
-            for (int idx = threadIdx.x; idx < nl * K0; idx += blockDim.x) {
-                const int l = idx / K0, n = idx - l * K0;
-                rout[(l0 + l) * K0 + n] = xa[l * xs + n].x;
-            }
-            __syncthreads();
-        }
-    }
-}
-
 // MODE 0: x forward (real lines -> half-complex), 4: x inverse; 1 / 3: y forward / inverse; 2: z forward, solve, z inverse
 template <int MODE, bool ENERGY>
 __global__ __launch_bounds__(256) void k_pme_fft(FftArgs A)
@@ -771,9 +432,10 @@ __global__ __launch_bounds__(256) void k_pme_fft(FftArgs A)
             }
         } else {
             for (int idx = threadIdx.x; idx < nl * K0c; idx += blockDim.x) {
-                const int l = idx / K0c, k = idx - l * K0c;
+                // (transposed layout: consecutive threads take consecutive lines, nl x 8 bytes contiguous per k_x)
+                const int l = A.tr ? idx % nl : idx / K0c, k = A.tr ? idx / nl : idx - l * K0c;
                 float2 v = make_float2(0.0f, 0.0f);
-                if (L0 + l < nlines) v = A.cgrid[(size_t)(L0 + l) * K0c + k];
+                if (L0 + l < nlines) v = A.tr ? A.cgrid[(size_t)k * nlines + L0 + l] : A.cgrid[(size_t)(L0 + l) * K0c + k];
                 a[l * stride + k] = v;
                 if (k > 0 && N - k >= K0c) a[l * stride + N - k] = make_float2(v.x, -v.y);
             }
@@ -782,8 +444,11 @@ __global__ __launch_bounds__(256) void k_pme_fft(FftArgs A)
         dft_lines_fast(a, b, Wl, nl, N, A.N1, A.N2, MODE == 4);
         if (MODE == 0) {
             for (int idx = threadIdx.x; idx < nl * K0c; idx += blockDim.x) {
-                const int l = idx / K0c, k = idx - l * K0c;
-                if (L0 + l < nlines) A.cgrid[(size_t)(L0 + l) * K0c + k] = a[l * stride + k];
+                const int l = A.tr ? idx % nl : idx / K0c, k = A.tr ? idx / nl : idx - l * K0c;
+                if (L0 + l < nlines) {
+                    if (A.tr) A.cgrid[(size_t)k * nlines + L0 + l] = a[l * stride + k];
+                    else A.cgrid[(size_t)(L0 + l) * K0c + k] = a[l * stride + k];
+                }
             }
         } else {
             for (int idx = threadIdx.x; idx < nl * N; idx += blockDim.x) {
@@ -858,6 +523,157 @@ __global__ __launch_bounds__(256) void k_pme_fft(FftArgs A)
     for (int idx = threadIdx.x; idx < nl * N; idx += blockDim.x) {
         const int n = idx / nl, c = idx - n * nl;
         if (kx0 + c < K0c) A.cgrid[base + (size_t)n * estride + kx0 + c] = a[c * stride + n];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// y and z transforms, influence function and the two inverse transforms of one k_x plane in one workgroup: with the
+// half-complex grid stored as (k_x, z, y) a plane is one contiguous block (36 KB for 80 x 56 points), it is read
+// once, transformed in LDS and written once, and the chain x -> (y, z, solve, z, y) -> x takes three launches instead
+// of five (each launch beside the nonbonded kernel costs 8-11 us whatever it computes, plus 2-4 us to the next).
+// The small DFTs are done in registers and IN PLACE: a line of N = N1 N2 points goes through
+//   pass 1  y[k1, n2] = W_N^(n2 k1) sum_n1 x[N2 n1 + n2] W_N1^(n1 k1)      on the positions {n2 + N2 j}
+//   pass 2  X[k1 + N1 k2] = sum_n2 y[k1, n2] W_N2^(n2 k2)                   on the positions {N2 k1 + j}
+// and the result stays where pass 2 computed it: position p holds the frequency p / N2 + N1 (p % N2). The influence
+// function is applied in that order, and the inverse runs the same passes backwards (pass 2, conjugate twiddle, pass 1),
+// which takes the permuted order as its input and ends in natural order. No scratch plane, no transposition.
+struct FftYzArgs {
+    float2 *cgrid;                      // (K0c, K2, K1), y fastest
+    const float2 *Wy, *Wz;              // exp(-2 pi i j / N) of the y and z dimensions
+    int K0, K1, K2, K0c;
+    int N1y, N2y, N1z, N2z;
+    const DevState *d; DevState *dw; const float *bm0, *bm1, *bm2; float beta;
+};
+// One R-point DFT per task on the elements p[j * rs], j < R, of `nlines` lines (line l at P + l * ls; consecutive threads
+// take consecutive lines, which keeps their LDS accesses on different banks for both directions of the plane) and `nsub`
+// sub-sequences per line (sub-sequence s at + s * ss). TW 1: output k times W^(+- s k) (forward pass 1); TW 2: input j
+// times W^(+- s j) (inverse pass 1); TW 0: none.
+template <int R, int TW>
+__device__ __forceinline__ void yz_pass(float2 *P, const float2 *W, int N, int nlines, int ls, int nsub, int ss, int rs, float sgn)
+{
+    float wr[R], wi[R];
+    dft_roots<R>(W, N, sgn, wr, wi);
+    for (int idx = threadIdx.x; idx < nlines * nsub; idx += blockDim.x) {
+        const int sub = idx / nlines, line = idx - sub * nlines;
+        float2 *p = P + line * ls + sub * ss;
+        float xr[R], xi[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            const float2 v = p[j * rs];
+            if (TW == 2 && j > 0) {
+                const float2 t = W[sub * j]; const float ty = sgn * t.y;
+                xr[j] = v.x * t.x - v.y * ty; xi[j] = v.x * ty + v.y * t.x;
+            } else { xr[j] = v.x; xi[j] = v.y; }
+        }
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            float re = xr[0], im = xi[0];
+#pragma unroll
+            for (int j = 1; j < R; j++) {
+                const int m = (j * k) % R;
+                re = fmaf(xr[j], wr[m], fmaf(-xi[j], wi[m], re));
+                im = fmaf(xr[j], wi[m], fmaf(xi[j], wr[m], im));
+            }
+            if (TW == 1 && k > 0) {
+                const float2 t = W[sub * k]; const float ty = sgn * t.y;
+                p[k * rs] = make_float2(re * t.x - im * ty, re * ty + im * t.x);
+            } else p[k * rs] = make_float2(re, im);
+        }
+    }
+}
+template <int R> __device__ __forceinline__ void yz_pass_tw_out(float2 *P, const float2 *W, int N, int nl, int ls, int nsub, int ss, int rs, float sgn) { yz_pass<R, 1>(P, W, N, nl, ls, nsub, ss, rs, sgn); }
+template <int R> __device__ __forceinline__ void yz_pass_tw_in(float2 *P, const float2 *W, int N, int nl, int ls, int nsub, int ss, int rs, float sgn) { yz_pass<R, 2>(P, W, N, nl, ls, nsub, ss, rs, sgn); }
+template <int R> __device__ __forceinline__ void yz_pass_plain(float2 *P, const float2 *W, int N, int nl, int ls, int nsub, int ss, int rs, float sgn) { yz_pass<R, 0>(P, W, N, nl, ls, nsub, ss, rs, sgn); }
+// all lines of one direction of the plane: element n of line l at P[l * ls + n * es]
+template <bool INVERSE>
+__device__ __forceinline__ void yz_lines(float2 *P, const float2 *W, int N, int N1, int N2, int nlines, int ls, int es)
+{
+    if (!INVERSE) {
+        switch (N1) { MDX_DFT_CASES(yz_pass_tw_out, P, W, N, nlines, ls, N2, es, N2 * es, 1.0f) }
+        __syncthreads();
+        switch (N2) { MDX_DFT_CASES(yz_pass_plain, P, W, N, nlines, ls, N1, N2 * es, es, 1.0f) }
+    } else {
+        switch (N2) { MDX_DFT_CASES(yz_pass_plain, P, W, N, nlines, ls, N1, N2 * es, es, -1.0f) }
+        __syncthreads();
+        switch (N1) { MDX_DFT_CASES(yz_pass_tw_in, P, W, N, nlines, ls, N2, es, N2 * es, -1.0f) }
+    }
+    __syncthreads();
+}
+#define MDX_YZ_THREADS 512
+template <bool ENERGY>
+__global__ __launch_bounds__(MDX_YZ_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_pme_fft_yz(FftYzArgs A)
+{
+    MDX_STAMP(A.d, 5);
+    extern __shared__ float2 fsm[];
+    const int K1 = A.K1, K2 = A.K2, ps = K1 + 1;
+    float2 *Wy = fsm, *Wz = Wy + K1, *P = Wz + K2;         // P[z * ps + y]
+    for (int j = threadIdx.x; j < K1; j += blockDim.x) Wy[j] = A.Wy[j];
+    for (int j = threadIdx.x; j < K2; j += blockDim.x) Wz[j] = A.Wz[j];
+    const int k0 = blockIdx.x;
+    float2 *plane = A.cgrid + (size_t)k0 * K1 * K2;
+    for (int idx = threadIdx.x; idx < K1 * K2; idx += blockDim.x) {
+        const int z = idx / K1, y = idx - z * K1;
+        P[z * ps + y] = plane[idx];
+    }
+    __syncthreads();
+    yz_lines<false>(P, Wy, K1, A.N1y, A.N2y, K2, ps, 1);
+    yz_lines<false>(P, Wz, K2, A.N1z, A.N2z, K1, 1, ps);
+    {
+        // influence function on position (pz, py), which holds the frequency (k1, k2) of the permuted order; energy and
+        // virial as in the stand-alone solve kernel
+        double e = 0.0, v[6] = { 0, 0, 0, 0, 0, 0 };
+        const float *iv = A.d->box.inv;
+        const float pi = 3.14159265358979f;
+        const float fac = pi * pi / (A.beta * A.beta);
+        const float pivol = pi * A.d->box.vol;
+        const int K0 = A.K0;
+        const float bm0 = A.bm0[k0];
+        for (int idx = threadIdx.x; idx < K1 * K2; idx += blockDim.x) {
+            const int pz = idx / K1, py = idx - pz * K1;
+            const int qy = py / A.N2y, qz = pz / A.N2z;
+            const int k1 = qy + A.N1y * (py - qy * A.N2y), k2 = qz + A.N1z * (pz - qz * A.N2z);
+            const int m0 = k0;
+            const int m1 = (k1 < (K1 + 1) / 2) ? k1 : k1 - K1;
+            const int m2 = (k2 < (K2 + 1) / 2) ? k2 : k2 - K2;
+            float2 cv = P[pz * ps + py];
+            if (m0 != 0 || m1 != 0 || m2 != 0) {
+                const float mx = iv[0] * m0 + iv[1] * m1 + iv[2] * m2;
+                const float my = iv[3] * m0 + iv[4] * m1 + iv[5] * m2;
+                const float mz = iv[6] * m0 + iv[7] * m1 + iv[8] * m2;
+                const float msq = mx * mx + my * my + mz * mz;
+                const float denom = msq * bm0 * A.bm1[k1] * A.bm2[k2] * pivol;
+                const float eterm = MDX_ONE_4PI_EPS0 * __expf(-fac * msq) / denom;
+                if (ENERGY) {
+                    const float mult = (k0 == 0 || (K0 % 2 == 0 && k0 == K0 / 2)) ? 1.0f : 2.0f;
+                    const double em = 0.5 * mult * (double)eterm * ((double)cv.x * cv.x + (double)cv.y * cv.y);
+                    e += em;
+                    const double vf = 2.0 * (1.0 + fac * msq) / msq;
+                    v[0] += em * (1.0 - vf * mx * mx); v[1] += em * (-vf * mx * my); v[2] += em * (-vf * mx * mz);
+                    v[3] += em * (1.0 - vf * my * my); v[4] += em * (-vf * my * mz); v[5] += em * (1.0 - vf * mz * mz);
+                }
+                cv.x *= eterm; cv.y *= eterm;
+            } else cv = make_float2(0.0f, 0.0f);
+            P[pz * ps + py] = cv;
+        }
+        if (ENERGY) {
+            __shared__ double red[16 * 7];
+            const double ev[7] = { e, v[0], v[1], v[2], v[3], v[4], v[5] };
+            const double r = block_sum_n<7>(ev, red);
+            const int map[6][2] = { { 0, 0 }, { 1, 3 }, { 2, 6 }, { 4, 4 }, { 5, 7 }, { 8, 8 } };
+            if (threadIdx.x == 0) atomicAdd(&MDX_ENER(A.dw, MDX_E_COUL_RECIP), r);
+            else if (threadIdx.x < 7) {
+                const int k = threadIdx.x - 1;
+                atomicAdd(&MDX_VIR(A.dw, map[k][0]), -0.5 * r);
+                if (map[k][1] != map[k][0]) atomicAdd(&MDX_VIR(A.dw, map[k][1]), -0.5 * r);
+            }
+        }
+        __syncthreads();
+    }
+    yz_lines<true>(P, Wz, K2, A.N1z, A.N2z, K1, 1, ps);
+    yz_lines<true>(P, Wy, K1, A.N1y, A.N2y, K2, ps, 1);
+    for (int idx = threadIdx.x; idx < K1 * K2; idx += blockDim.x) {
+        const int z = idx / K1, y = idx - z * K1;
+        plane[idx] = P[z * ps + y];
     }
 }
 
@@ -962,9 +778,16 @@ int mdx_pme_init(mdx_system *s)
         MDX_CHECK(s, hipMalloc((void **)&s->fftW[d], sizeof(float2) * s->K[d]));
         MDX_CHECK(s, hipMemcpy(s->fftW[d], w.data(), sizeof(float2) * s->K[d], hipMemcpyHostToDevice));
     }
-    // the plane kernels may ask for more than the default 64 KB of dynamic LDS
-    MDX_CHECK(s, hipFuncSetAttribute((const void *)k_pme_fft2d<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-    MDX_CHECK(s, hipFuncSetAttribute((const void *)k_pme_fft2d<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    {
+        int a1, a2, b1, b2;
+        const size_t ldsy = sizeof(float2) * ((size_t)s->K[1] + s->K[2] + (size_t)s->K[2] * (s->K[1] + 1));
+        s->fft_yz = s->own_fft && fft_split(s->K[1], a1, a2) && fft_split(s->K[2], b1, b2) && a1 >= 2 && b1 >= 2 &&
+                    a2 <= MDX_DFT_MAXR && b2 <= MDX_DFT_MAXR && ldsy <= 96 * 1024;
+        if (s->fft_yz && ldsy > 48 * 1024) {
+            MDX_CHECK(s, hipFuncSetAttribute((const void *)k_pme_fft_yz<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsy));
+            MDX_CHECK(s, hipFuncSetAttribute((const void *)k_pme_fft_yz<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsy));
+        }
+    }
     s->have_pme = true;
     return MDX_OK;
 }
@@ -981,177 +804,108 @@ void mdx_pme_free(mdx_system *s)
     s->have_pme = false;
 }
 
-// Zero the charge grid and spread onto it, on stream `st`. With `signal` the spread kernel's completion
-// releases the PME stream (the spread then ran on the main stream, ahead of the nonbonded kernel and at
-// the full width of the GPU, instead of competing with that kernel for LDS and wave slots).
-int mdx_launch_pme_spread(mdx_system *s, hipStream_t st, bool signal)
+// Zero the charge grid (unless the last transform's x pass left it zeroed) and spread onto it, on stream `st`.
+int mdx_launch_pme_spread(mdx_system *s, hipStream_t st)
 {
     if (!s->have_pme) return MDX_OK;
     const int K0 = s->K[0], K1 = s->K[1], K2 = s->K[2];
     const size_t nr = (size_t)K0 * K1 * K2;
-    // the own transform's x pass leaves the charge grid zeroed; otherwise clear it here
     if (!s->grid_clean) MDX_CHECK(s, hipMemsetAsync(s->grid, 0, sizeof(float) * nr, st));
     s->grid_clean = false;
-    {
-        // window sizes from the column geometry (host copy of the box; a drift margin covers the rest)
-        const double *bxd = s->h->boxd;
-        const double inv0 = 1.0 / bxd[0], inv4 = 1.0 / bxd[4], inv8 = 1.0 / bxd[8];
-        const double inv3 = -bxd[3] * inv0 * inv4, inv6 = (bxd[3] * bxd[7] - bxd[4] * bxd[6]) * inv0 * inv4 * inv8, inv7 = -bxd[7] * inv4 * inv8;
-        const double delta = 0.12;
-        const double wx = bxd[0] / s->ncx + 2 * delta, wy = bxd[4] / s->ncy + 2 * delta, wz = 4.0 / (K2 * inv8) + 2 * delta;
-        SpreadArgs A;
-        A.ncx = s->ncx; A.ncy = s->ncy; A.col_scstart = s->col_scstart; A.x = s->x; A.perm = s->perm; A.perm_src = s->perm_src; A.shift_s = s->shift_s; A.K0 = K0; A.K1 = K1; A.K2 = K2;
-        A.T0 = std::min(K0, (int)ceil(K0 * (inv0 * wx + fabs(inv3) * wy + fabs(inv6) * wz)) + 5);
-        A.T1 = std::min(K1, (int)ceil(K1 * (inv4 * wy + fabs(inv7) * wz)) + 5);
-        const int planes = K2 + 8;
-        // slabs of planes so that a tile stays below ~48 KB and the launch has enough workgroups
-        int nchunk = 1;
-        static const size_t tile_kb = getenv("MDX_SPREAD_LDS_KB") ? (size_t)atoi(getenv("MDX_SPREAD_LDS_KB")) : 48;
-        static const int min_wg = getenv("MDX_SPREAD_MIN_WG") ? atoi(getenv("MDX_SPREAD_MIN_WG")) : 512;
-        while ((size_t)((planes + nchunk - 1) / nchunk) * A.T0 * A.T1 * 4 > tile_kb * 1024 || (s->ncx * s->ncy * nchunk < min_wg && nchunk < 16)) nchunk++;
-        A.ppc = (planes + nchunk - 1) / nchunk;
-        A.delta = (float)delta; A.grid = s->grid; A.v_home = s->dd_on ? s->v : nullptr;
-        if (getenv("MDX_PME_NOTILE")) { A.T0 = 4; A.T1 = 4; }
-        static const bool use_col = getenv("MDX_SPREAD") && !strcmp(getenv("MDX_SPREAD"), "col");
-        static const bool use_chunk = getenv("MDX_SPREAD") && !strcmp(getenv("MDX_SPREAD"), "chunk");
-        static const int spread_abl = getenv("MDX_SPREAD_ABL") ? atoi(getenv("MDX_SPREAD_ABL")) : 0;
-        if (!use_col && !use_chunk) {
-            static const int qx = getenv("MDX_SPREAD_QX") ? atoi(getenv("MDX_SPREAD_QX")) : 2;
-            static const int qy = getenv("MDX_SPREAD_QY") ? atoi(getenv("MDX_SPREAD_QY")) : 2;
-            static const int sp = getenv("MDX_SPREAD_SP") ? atoi(getenv("MDX_SPREAD_SP")) : 8;
-            SpreadSlabArgs B;
-            B.ncx = s->ncx; B.ncy = s->ncy; B.qx = std::max(1, qx); B.qy = std::max(1, qy);
-            while (B.qx * B.qy * (MDX_MAX_COL / 64) > MDX_SPREAD_MAXSC) { if (B.qx >= B.qy) B.qx--; else B.qy--; }
-            B.col_scstart = s->col_scstart; B.x = s->x; B.perm = s->perm; B.perm_src = s->perm_src; B.shift_s = s->shift_s;
-            B.sbb_lo = s->sbb_lo; B.sbb_hi = s->sbb_hi; B.K0 = K0; B.K1 = K1; B.K2 = K2; B.SP = std::max(2, sp);
-            const double wxq = B.qx * bxd[0] / s->ncx + 2 * delta, wyq = B.qy * bxd[4] / s->ncy + 2 * delta;
-            B.T0 = std::min(K0, (int)ceil(K0 * (inv0 * wxq + fabs(inv3) * wyq + fabs(inv6) * wz)) + 5);
-            B.T1 = std::min(K1, (int)ceil(K1 * (inv4 * wyq + fabs(inv7) * wz)) + 5);
-            while ((size_t)B.SP * B.T0 * B.T1 * 4 > 60 * 1024 && B.SP > 2) B.SP--;
-            // Unwrapped planes an atom of the brick can touch: -1 .. K2 + 3 with a drift of less than a plane (the
-            // margin of 0.12 nm); the slabs cover -4 .. K2 + 7 at least, three planes (0.47 nm) more on either side.
-            B.tlo0 = -4;
-            const int nslab = (K2 + 12 + B.SP - 1) / B.SP;
-            B.abl = spread_abl & 3; B.delta = (float)delta; B.grid = s->grid; B.v_home = s->dd_on ? s->v : nullptr;
-            const size_t ldss = (size_t)B.SP * B.T0 * B.T1 * 4 + (size_t)B.SP * 16;
-            const int nq = ((s->ncx + B.qx - 1) / B.qx) * ((s->ncy + B.qy - 1) / B.qy);
-            hipLaunchKernelGGL(k_pme_spread_slab, dim3(nq, nslab), dim3(256), ldss, st, B, (const DevState *)s->d);
-        } else if (!use_col) {
-            SpreadChunkArgs C;
-            C.ncx = s->ncx; C.ncy = s->ncy; C.col_scstart = s->col_scstart; C.x = s->x; C.perm = s->perm; C.perm_src = s->perm_src;
-            C.shift_s = s->shift_s; C.sbb_lo = s->sbb_lo; C.sbb_hi = s->sbb_hi; C.K0 = K0; C.K1 = K1; C.K2 = K2; C.T0 = A.T0; C.T1 = A.T1;
-            C.sc_per_chunk = 4;
-            C.abl = spread_abl & 3;
-            // planes a chunk of four super-clusters reaches: their height (a super-cluster of 64 atoms is about as tall
-            // as a column is wide; taller ones in thin regions fall back to the grid) plus the spline support and the margin
-            const double sc_h = std::cbrt(64.0 * (bxd[0] * bxd[4] * bxd[8]) / std::max(1, s->n));
-            C.PPC = std::min(K2 + 8, (int)ceil((C.sc_per_chunk * sc_h * 1.15 + 2 * delta) * K2 * inv8) + 5);
-            while ((size_t)C.PPC * C.T0 * C.T1 * 4 > 60 * 1024 && C.PPC > 8) C.PPC--;
-            C.delta = (float)delta; C.grid = s->grid; C.v_home = s->dd_on ? s->v : nullptr;
-            const size_t ldsc = (size_t)C.PPC * C.T0 * C.T1 * 4 + (size_t)C.PPC * 16;
-            // columns hold at most MDX_MAX_COL atoms = 32 super-clusters
-            const int ychunks = (MDX_MAX_COL / 64 + C.sc_per_chunk - 1) / C.sc_per_chunk;
-            hipLaunchKernelGGL(k_pme_spread_chunk, dim3(s->ncx * s->ncy, ychunks), dim3(256), ldsc, st, C, (const DevState *)s->d);
-        } else {
-        const size_t lds = (size_t)A.ppc * A.T0 * A.T1 * 4 + (size_t)A.ppc * 8;
-        hipLaunchKernelGGL(k_pme_spread_col, dim3(s->ncx * s->ncy, nchunk), dim3(256), lds, st, A, (const DevState *)s->d);
-        }
-        MDX_CHECK(s, hipGetLastError());
-        if (signal) {
-            // a marker behind the kernel (a completion signal on the kernel itself holds the next kernel of this queue back by ~19 us)
-            MDX_CHECK(s, hipEventRecord(s->ev_spread, st));
-            MDX_CHECK(s, hipStreamWaitEvent(s->st_pme, s->ev_spread, 0));
-        }
-    }
-    return MDX_OK;
-}
-
-// The gather deferred to the main stream (see gather_on_main): called by the join once that stream waits for the transforms.
-int mdx_launch_pme_gather_pending(mdx_system *s)
-{
-    if (!s->gather_pending) return MDX_OK;
-    const int nb = (int)(((size_t)s->n * 16 + 255) / 256);
-    hipLaunchKernelGGL(k_pme_gather, dim3(nb), dim3(256), 0, s->stream, s->n, (const float4 *)s->x, (const DevState *)s->d,
-                       s->K[0], s->K[1], s->K[2], s->gather_pending, s->f_pme);
-    s->gather_pending = nullptr;
+    // window sizes from the column geometry (host copy of the box; a drift margin covers the rest)
+    const double *bxd = s->h->boxd;
+    const double inv0 = 1.0 / bxd[0], inv4 = 1.0 / bxd[4], inv8 = 1.0 / bxd[8];
+    const double inv3 = -bxd[3] * inv0 * inv4, inv6 = (bxd[3] * bxd[7] - bxd[4] * bxd[6]) * inv0 * inv4 * inv8, inv7 = -bxd[7] * inv4 * inv8;
+    const double delta = 0.12;
+    const double wz = 4.0 / (K2 * inv8) + 2 * delta;
+    SpreadSlabArgs B;
+    // 2 x 2 search columns and 8 planes per workgroup (measured best on the bench workload among 1-3 columns, 4-12 planes)
+    B.ncx = s->ncx; B.ncy = s->ncy; B.qx = 2; B.qy = 2;
+    while (B.qx * B.qy * (MDX_MAX_COL / 64) > MDX_SPREAD_MAXSC) { if (B.qx >= B.qy) B.qx--; else B.qy--; }
+    B.col_scstart = s->col_scstart; B.x = s->x; B.perm = s->perm; B.perm_src = s->perm_src; B.shift_s = s->shift_s;
+    B.sbb_lo = s->sbb_lo; B.sbb_hi = s->sbb_hi; B.K0 = K0; B.K1 = K1; B.K2 = K2; B.SP = 8;
+    const double wxq = B.qx * bxd[0] / s->ncx + 2 * delta, wyq = B.qy * bxd[4] / s->ncy + 2 * delta;
+    B.T0 = std::min(K0, (int)ceil(K0 * (inv0 * wxq + fabs(inv3) * wyq + fabs(inv6) * wz)) + 5);
+    B.T1 = std::min(K1, (int)ceil(K1 * (inv4 * wyq + fabs(inv7) * wz)) + 5);
+    while ((size_t)B.SP * B.T0 * B.T1 * 4 > 60 * 1024 && B.SP > 2) B.SP--;
+    // Unwrapped planes an atom of the brick can touch: -1 .. K2 + 3 with a drift of less than a plane (the
+    // margin of 0.12 nm); the slabs cover -4 .. K2 + 7 at least, three planes (0.47 nm) more on either side.
+    B.tlo0 = -4;
+    const int nslab = (K2 + 12 + B.SP - 1) / B.SP;
+    B.delta = (float)delta; B.grid = s->grid; B.v_home = s->dd_on ? s->v : nullptr;
+    const size_t ldss = (size_t)B.SP * B.T0 * B.T1 * 4 + (size_t)B.SP * 16;
+    const int nq = ((s->ncx + B.qx - 1) / B.qx) * ((s->ncy + B.qy - 1) / B.qy);
+    hipLaunchKernelGGL(k_pme_spread_slab, dim3(nq, nslab), dim3(256), ldss, st, B, (const DevState *)s->d);
     MDX_CHECK(s, hipGetLastError());
     return MDX_OK;
 }
 
+// The PME chain on the PME stream: spreading (unless the caller has done it), transforms with the influence function,
+// gather; the gather's completion signal is the event the main stream waits for. `s->pme_part` (stage timing only)
+// restricts the chain to the spreading (1) or the gather (2).
 int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done)
 {
     if (!s->have_pme) return MDX_OK;
     const int K0 = s->K[0], K1 = s->K[1], K2 = s->K[2];
     const size_t ncx = (size_t)K2 * K1 * (K0 / 2 + 1);
     const int nb = (int)(((size_t)s->n * 16 + 255) / 256);
-    if (s->dbg & 2048) {       // diagnostic: the gather alone (stage timing)
+    if (s->pme_part == 2) {
         hipLaunchKernelGGL(k_pme_gather, dim3(nb), dim3(256), 0, s->st_pme, s->n, (const float4 *)s->x, (const DevState *)s->d, K0, K1, K2,
                            (const float *)(s->own_fft ? s->phi : s->grid), s->f_pme);
         MDX_CHECK(s, hipGetLastError());
         return MDX_OK;
     }
-    if (!spread_done) { int rc = mdx_launch_pme_spread(s, s->st_pme, false); if (rc) return rc; }
-    if (s->dbg & 256) { MDX_CHECK(s, hipGetLastError()); return MDX_OK; }       // diagnostic: spreading only
+    if (!spread_done) { int rc = mdx_launch_pme_spread(s, s->st_pme); if (rc) return rc; }
+    if (s->pme_part == 1) return MDX_OK;
     const float *potential = s->grid;       // the library path transforms in place
     if (s->own_fft && !(s->dbg & 512)) {
         FftArgs F;
         F.grid_in = s->grid; F.grid_out = s->phi; F.cgrid = s->cgrid; F.K0 = K0; F.K1 = K1; F.K2 = K2; F.K0c = K0 / 2 + 1;
         F.d = s->d; F.dw = s->d; F.bm0 = s->bmod[0]; F.bm1 = s->bmod[1]; F.bm2 = s->bmod[2]; F.beta = s->beta;
         auto lds = [](const FftArgs &f) { return sizeof(float2) * ((size_t)f.N + 2 * (size_t)f.nl * (f.N + 1)); };
-        static const int ynl0 = getenv("MDX_FFT_YNL") ? atoi(getenv("MDX_FFT_YNL")) : 8;
-        static const int xnl = getenv("MDX_FFT_XNL") ? atoi(getenv("MDX_FFT_XNL")) : 16;
-        const int nchunk = (F.K0c + ynl0 - 1) / ynl0;
-        Fft2Args G;
-        G.grid_in = s->grid; G.grid_out = s->phi; G.cgrid = s->cgrid; G.W0 = s->fftW[0]; G.W1 = s->fftW[1]; G.K0 = K0; G.K1 = K1; G.K0c = F.K0c;
-        fft_split(K0, G.N01, G.N02); fft_split(K1, G.N11, G.N12);
-        const size_t lds2 = sizeof(float2) * ((size_t)K0 + K1 + 2 * (size_t)K1 * (F.K0c + 1) + 2 * (size_t)MDX_FFT_XB * (K0 + 1));
-        // measured slower than the per-direction passes at 80x80x56 (one workgroup per plane: 56 workgroups, 35 us per
-        // launch beside the nonbonded kernel against 19 + 6 us): off unless asked for (mdx_debug_set key 2, bit 0x2000000)
-        const bool planes = lds2 <= 100 * 1024 && (s->dbg & 0x2000000);
-        if (planes) {
-            // x and y forward, one workgroup per plane
-            hipLaunchKernelGGL(k_pme_fft2d<false>, dim3(K2), dim3(512), lds2, s->st_pme, G, (const DevState *)s->d);
-        } else {
+        const int ynl = 8, xnl = 16;        // lines per workgroup: 64 and 128 bytes contiguous per access of the strided side
+        const int nchunk = (F.K0c + ynl - 1) / ynl;
+        // one workgroup per k_x plane for the y and z passes where a plane fits into LDS and both dimensions split into
+        // two factors <= 10 (mdx_debug_set key 2 bit 0x2000000 keeps the pass-per-launch form: cross-check and A/B)
+        const bool fused_yz = s->fft_yz && !(s->dbg & 0x2000000);
+        F.tr = fused_yz ? 1 : 0;
         // x forward
         F.N = K0; fft_split(K0, F.N1, F.N2); F.W = s->fftW[0]; F.nl = xnl;
         hipLaunchKernelGGL((k_pme_fft<0, false>), dim3((K1 * K2 + F.nl - 1) / F.nl), dim3(256), lds(F), s->st_pme, F);
-        // y forward
-        F.N = K1; fft_split(K1, F.N1, F.N2); F.W = s->fftW[1]; F.nl = ynl0;
-        hipLaunchKernelGGL((k_pme_fft<1, false>), dim3(K2 * nchunk), dim3(256), lds(F), s->st_pme, F);
-        }
-        // z forward, influence function, z inverse
-        F.N = K2; fft_split(K2, F.N1, F.N2); F.W = s->fftW[2]; F.nl = ynl0;
-        if (energy) hipLaunchKernelGGL((k_pme_fft<2, true>), dim3(K1 * nchunk), dim3(256), lds(F), s->st_pme, F);
-        else hipLaunchKernelGGL((k_pme_fft<2, false>), dim3(K1 * nchunk), dim3(256), lds(F), s->st_pme, F);
-        if (planes) {
-            hipLaunchKernelGGL(k_pme_fft2d<true>, dim3(K2), dim3(512), lds2, s->st_pme, G, (const DevState *)s->d);
+        if (fused_yz) {
+            FftYzArgs Y;
+            Y.cgrid = s->cgrid; Y.Wy = s->fftW[1]; Y.Wz = s->fftW[2]; Y.K0 = K0; Y.K1 = K1; Y.K2 = K2; Y.K0c = F.K0c;
+            fft_split(K1, Y.N1y, Y.N2y); fft_split(K2, Y.N1z, Y.N2z);
+            Y.d = s->d; Y.dw = s->d; Y.bm0 = s->bmod[0]; Y.bm1 = s->bmod[1]; Y.bm2 = s->bmod[2]; Y.beta = s->beta;
+            const size_t ldsy = sizeof(float2) * ((size_t)K1 + K2 + (size_t)K2 * (K1 + 1));
+            if (energy) hipLaunchKernelGGL(k_pme_fft_yz<true>, dim3(F.K0c), dim3(MDX_YZ_THREADS), ldsy, s->st_pme, Y);
+            else hipLaunchKernelGGL(k_pme_fft_yz<false>, dim3(F.K0c), dim3(MDX_YZ_THREADS), ldsy, s->st_pme, Y);
         } else {
-        // y inverse
-        F.N = K1; fft_split(K1, F.N1, F.N2); F.W = s->fftW[1]; F.nl = ynl0;
-        hipLaunchKernelGGL((k_pme_fft<3, false>), dim3(K2 * nchunk), dim3(256), lds(F), s->st_pme, F);
+            // y forward
+            F.N = K1; fft_split(K1, F.N1, F.N2); F.W = s->fftW[1]; F.nl = ynl;
+            hipLaunchKernelGGL((k_pme_fft<1, false>), dim3(K2 * nchunk), dim3(256), lds(F), s->st_pme, F);
+            // z forward, influence function, z inverse
+            F.N = K2; fft_split(K2, F.N1, F.N2); F.W = s->fftW[2]; F.nl = ynl;
+            if (energy) hipLaunchKernelGGL((k_pme_fft<2, true>), dim3(K1 * nchunk), dim3(256), lds(F), s->st_pme, F);
+            else hipLaunchKernelGGL((k_pme_fft<2, false>), dim3(K1 * nchunk), dim3(256), lds(F), s->st_pme, F);
+            // y inverse
+            F.N = K1; fft_split(K1, F.N1, F.N2); F.W = s->fftW[1]; F.nl = ynl;
+            hipLaunchKernelGGL((k_pme_fft<3, false>), dim3(K2 * nchunk), dim3(256), lds(F), s->st_pme, F);
+        }
         // x inverse
         F.N = K0; fft_split(K0, F.N1, F.N2); F.W = s->fftW[0]; F.nl = xnl;
         hipLaunchKernelGGL((k_pme_fft<4, false>), dim3((K1 * K2 + F.nl - 1) / F.nl), dim3(256), lds(F), s->st_pme, F);
-        }
         s->grid_clean = true;
         potential = s->phi;
     } else {
-    hipfftSetStream(s->plan_r2c, s->st_pme); hipfftSetStream(s->plan_c2r, s->st_pme);     // the streams may have changed roles
-    if (hipfftExecR2C(s->plan_r2c, s->grid, (hipfftComplex *)s->cgrid) != HIPFFT_SUCCESS) { s->err = "hipfftExecR2C failed"; return MDX_ERR_HIP; }
-    const int nbs = (int)((ncx + 255) / 256);
-    if (energy)
-        hipLaunchKernelGGL(k_pme_solve<true>, dim3(nbs), dim3(256), 0, s->st_pme, s->cgrid, s->d, s->d, K0, K1, K2, s->bmod[0], s->bmod[1], s->bmod[2], s->beta);
-    else
-        hipLaunchKernelGGL(k_pme_solve<false>, dim3(nbs), dim3(256), 0, s->st_pme, s->cgrid, s->d, s->d, K0, K1, K2, s->bmod[0], s->bmod[1], s->bmod[2], s->beta);
-    if (hipfftExecC2R(s->plan_c2r, (hipfftComplex *)s->cgrid, s->grid) != HIPFFT_SUCCESS) { s->err = "hipfftExecC2R failed"; return MDX_ERR_HIP; }
-    }
-    if (s->gather_on_main) {
-        // the gather follows the nonbonded kernel in the main queue (released by the end of the transforms): the update
-        // then starts one in-queue gap after it instead of one cross-queue wake-up after the PME stream
-        MDX_CHECK(s, hipEventRecord(s->ev_pme, s->st_pme));
-        s->pme_signalled = true;
-        s->gather_pending = potential;
-        return MDX_OK;
+        hipfftSetStream(s->plan_r2c, s->st_pme); hipfftSetStream(s->plan_c2r, s->st_pme);
+        if (hipfftExecR2C(s->plan_r2c, s->grid, (hipfftComplex *)s->cgrid) != HIPFFT_SUCCESS) { s->err = "hipfftExecR2C failed"; return MDX_ERR_HIP; }
+        const int nbs = (int)((ncx + 255) / 256);
+        if (energy)
+            hipLaunchKernelGGL(k_pme_solve<true>, dim3(nbs), dim3(256), 0, s->st_pme, s->cgrid, s->d, s->d, K0, K1, K2, s->bmod[0], s->bmod[1], s->bmod[2], s->beta);
+        else
+            hipLaunchKernelGGL(k_pme_solve<false>, dim3(nbs), dim3(256), 0, s->st_pme, s->cgrid, s->d, s->d, K0, K1, K2, s->bmod[0], s->bmod[1], s->bmod[2], s->beta);
+        if (hipfftExecC2R(s->plan_c2r, (hipfftComplex *)s->cgrid, s->grid) != HIPFFT_SUCCESS) { s->err = "hipfftExecC2R failed"; return MDX_ERR_HIP; }
     }
     // the completion signal of the last kernel of the chain is the event the main stream waits for
     hipExtLaunchKernelGGL(k_pme_gather, dim3(nb), dim3(256), 0, s->st_pme, nullptr, s->ev_pme, 0, s->n, (const float4 *)s->x,

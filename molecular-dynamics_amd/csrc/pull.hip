@@ -119,7 +119,7 @@ int mdx_launch_pull(mdx_system *s, bool log_now, bool energy)
     P.time = (double)s->step * s->dt; P.dt = s->dt;
     P.log = s->pull_log; P.log_cap = s->pull_log_cap; P.log_slot = s->pull_log_count; P.log_now = log_now ? 1 : 0;
     P.energy = energy ? 1 : 0;
-    hipLaunchKernelGGL(k_pull, dim3(1), dim3(256), 0, (s->bond_on_main ? s->stream : s->st_bond), P, s->x, s->v, s->f, s->d);
+    hipLaunchKernelGGL(k_pull, dim3(1), dim3(256), 0, s->st_bond, P, s->x, s->v, s->f, s->d);
     MDX_CHECK(s, hipGetLastError());
     if (log_now) s->pull_log_count++;
     return MDX_OK;

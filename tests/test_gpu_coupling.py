@@ -180,7 +180,9 @@ def test_dispersion_correction_energy_and_pressure(small_complex):
     assert np.abs(res[1][1] - res[0][1]).max() < 1e-6 * np.abs(res[0][1]).max()
     d = res[2][1] - res[0][1]
     assert np.abs(np.diag(d) - p_disp).max() < 1e-5 * abs(p_disp)
-    assert np.abs(d - np.diag(np.diag(d))).max() < 1e-6 * abs(p_disp)
+    # (two separate evaluations: the off-diagonal elements differ by the float32 summation noise of the pair virial, whose
+    # order of accumulation is not fixed; 3e-4 bar has been seen)
+    assert np.abs(d - np.diag(np.diag(d))).max() < 5e-6 * abs(p_disp)
 
 
 def test_com_motion_removal_matches_oracle(small_water):

@@ -31,7 +31,7 @@ def test_own_transform_matches_oracle_and_library(grid, small_water):
         f_lib, en_lib = e.compute(eng.F_PME)
         assert relrms(f_own, f_lib) < 3e-6
         assert abs(en_own["COUL_RECIP"] - en_lib["COUL_RECIP"]) < 1e-6 * abs(Ep)
-        e.debug_set(2, 0x2000000)           # per-plane x+y kernels
+        e.debug_set(2, 0x2000000)           # y and z passes as separate launches (the default fuses them per k_x plane)
         f_pl, en_pl = e.compute(eng.F_PME)
         assert relrms(f_pl, Fp) < 1e-5
         assert abs(en_pl["COUL_RECIP"] - Ep) < 1e-5 * abs(Ep)

@@ -12,8 +12,7 @@ e.step(500); e.synchronize()
 print("rlist", e.rlist, e.list_stats())
 for dyn, sp in ((0, 0), (1, 0), (1, 1), (1, 2), (1, 3), (2, 1), (2, 2), (2, 3), (3, 2)):
     e.debug_set(3, dyn); e.debug_set(4, sp)
-    print("dyn %d split %d: alone %.1f us (f3)  " % (dyn, sp, e.debug_time_nonbonded(False, 30) * 1e3), end="")
-    e.debug_set(1, 34); print("%.1f us (f4)  " % (e.debug_time_nonbonded(False, 30) * 1e3), end=""); e.debug_set(1, 33)
+    print("dyn %d split %d: alone %.1f us (force)  " % (dyn, sp, e.debug_time_nonbonded(False, 30) * 1e3), end="")
     print("%.1f us (energy)" % (e.debug_time_nonbonded(True, 30) * 1e3))
 for rep, (dyn, sp) in enumerate(((1, 2), (2, 2))):
     e.debug_set(3, dyn); e.debug_set(4, sp)

@@ -6,7 +6,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, mdx
 from mdx import synth, engine as eng
-NAMES = {0: "prepare", 1: "nonbonded", 2: "nonbonded (energy)", 3: "spread", 4: "fft x", 5: "fft y", 6: "fft z+solve", 7: "fft y inv",
+NAMES = {0: "prepare", 1: "nonbonded", 2: "nonbonded (energy)", 3: "spread", 4: "fft x", 5: "fft y (or y+z fused)", 6: "fft z+solve", 7: "fft y inv",
          8: "fft x inv", 9: "gather", 10: "bonded", 11: "leapfrog / fused update", 12: "settle", 13: "lincs", 15: "tcouple", 17: "build list"}
 s = synth.pseudo_complex(d=12.5)
 tc = ["Protein", "Non-Protein"]

@@ -194,3 +194,56 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def pairing_stats(x, L, member, sc_of, rc, rlist):
+    """For the engine's clustering: how many of an entry's listed tiles pair up when the eight i-clusters of a super-cluster
+    are evaluated two at a time, for the three static pairings (partner = the cluster's x, y or z neighbour inside the
+    super-cluster: cluster index bit 0, 1 or 2)."""
+    valid = member >= 0
+    pos = np.where(valid[:, :, None], x[np.where(valid, member, 0)], np.nan)
+    ctr = np.nanmean(pos, axis=1)
+    rad = np.sqrt(np.nanmax(((pos - ctr[:, None, :]) ** 2).sum(-1), axis=1))
+    tree = cKDTree(np.mod(ctr, L), boxsize=L)
+    pairs = tree.query_pairs(rlist + 2 * rad.max(), output_type="ndarray")
+    first = np.zeros(sc_of.max() + 2, dtype=np.int64)
+    np.add.at(first, sc_of + 1, 1); first = np.cumsum(first)
+    cin = np.arange(len(sc_of)) - first[sc_of]            # cluster index inside its super-cluster
+    keys, bits = [], []
+    for s in range(0, len(pairs), 200000):
+        p = pairs[s:s + 200000]
+        a, b = p[:, 0], p[:, 1]
+        d = pos[a][:, :, None, :] - pos[b][:, None, :, :]
+        d -= L * np.round(d / L)
+        r2 = np.where(np.isnan((d * d).sum(-1)), 1e9, (d * d).sum(-1))
+        listed = (r2 < rlist * rlist).any((1, 2))
+        a, b = a[listed], b[listed]
+        sa, sb = sc_of[a], sc_of[b]
+        ic = np.where(sa <= sb, a, b); jc = np.where(sa <= sb, b, a)
+        keys.append(sc_of[ic].astype(np.int64) * (1 << 32) + jc); bits.append(1 << cin[ic])
+    keys = np.concatenate(keys); bits = np.concatenate(bits)
+    order = np.argsort(keys, kind="stable"); keys = keys[order]; bits = bits[order]
+    uniq, start = np.unique(keys, return_index=True)
+    masks = np.bitwise_or.reduceat(bits, start)
+    ntiles = sum(int(((masks >> c) & 1).sum()) for c in range(8))
+    out = {}
+    for bit, name in ((0, "x neighbour"), (1, "y neighbour"), (2, "z neighbour")):
+        paired = 0
+        for c in range(8):
+            if c & (1 << bit):
+                continue
+            both = ((masks >> c) & 1) & ((masks >> (c | (1 << bit))) & 1)
+            paired += 2 * int(both.sum())
+        out[name] = paired / ntiles
+    return len(uniq), ntiles, out
+
+
+if __name__ == "__main__" and os.environ.get("TILE_MODEL_PAIRING"):
+    L = 6.0
+    s = synth.water_box(box=np.diag([L, L, L]), jitter=0.03)
+    x = np.mod(s.x, L)
+    member, sc_of = build(x, L, s.natoms / L ** 3, "zyx", s.eps > 0)
+    for rl in (1.041, 1.095):
+        n, nt, o = pairing_stats(x, L, member, sc_of, 1.0, rl)
+        print("rlist %.3f: %d entries, %d listed tiles (%.2f per entry); fraction of tiles that pair up:" % (rl, n, nt, nt / n),
+              ", ".join("%s %.3f" % kv for kv in o.items()))
