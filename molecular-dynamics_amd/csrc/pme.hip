@@ -271,6 +271,20 @@ __global__ __launch_bounds__(256) void k_pme_solve(float2 *__restrict__ cgrid, c
 // arithmetic is negligible against the launch). Passes: x (real to half-complex), y, z forward +
 // influence function + z inverse in one kernel, y inverse, x inverse (half-complex to real).
 // Unnormalised in both directions, layout of cgrid (K2, K1, K0/2+1) as hipFFT's R2C plan.
+// Element-wise copy loops of the transform kernels with B loads of a thread in flight at a time: a plain loop issues one
+// load, waits for it (a trip to the L2 or beyond: the data was written by another kernel) and stores, once per trip.
+template <int B, class T, class Load, class Store>
+__device__ __forceinline__ void copy_batched(const int n, Load &&ld, Store &&st)
+{
+    const int nt = blockDim.x;
+    for (int base = threadIdx.x; base < n; base += B * nt) {
+        T v[B];
+#pragma unroll
+        for (int u = 0; u < B; u++) { const int i = base + u * nt; if (i < n) v[u] = ld(i); }
+#pragma unroll
+        for (int u = 0; u < B; u++) { const int i = base + u * nt; if (i < n) st(i, v[u]); }
+    }
+}
 struct FftArgs {
     float *grid_in; float *grid_out; float2 *cgrid;   // x forward reads grid_in and leaves it zeroed for the next spreading
     const float2 *W;            // exp(-2 pi i j / N), j < N, of the transformed dimension
@@ -326,8 +340,8 @@ __device__ __forceinline__ void dft_lines(float2 *a, float2 *b, const float2 *W,
 
 // The same transform with the small DFTs of a pass done by one thread each: a thread loads the R inputs of one small DFT
 // into registers once and forms its R outputs from them, the R-th roots of unity in scalar registers (they are the same
-// for every lane) and every index known at compile time. That is 4 R multiply-adds per output point and one LDS read per
-// input point, where the one-output-per-thread form above spends about ten instructions and two LDS reads per
+// for every lane) and every index known at compile time. That is about R multiply-adds per output point (dft_small) and one
+// LDS read per input point, where the one-output-per-thread form above spends about ten instructions and two LDS reads per
 // multiply-add on loads and index arithmetic - and the transforms run beside the nonbonded kernel, which leaves them few
 // issue slots. Radices up to 10 (every factor pair of the PME grids up to 100 points); other lines take the form above.
 #define MDX_DFT_MAXR 10
@@ -340,6 +354,49 @@ __device__ __forceinline__ void dft_roots(const float2 *W, int N, float sgn, flo
         const float2 w = W[m * (N / R)];
         wr[m] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w.x)));
         wi[m] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sgn * w.y)));
+    }
+}
+// R-point DFT of register values, X_k = sum_j x_j w^(jk) with w^m = wr[m] + i wi[m]. The inputs j and R - j meet the same
+// cosine and opposite sines, for the outputs k and R - k alike: with s_j = x_j + x_(R-j), d_j = x_j - x_(R-j),
+// A_k = x_0 (+- x_(R/2)) + sum_j s_j wr[jk] and B_k = sum_j d_j wi[jk] (j = 1 .. (R-1)/2) the outputs are
+// X_k = A_k + i B_k and X_(R-k) = A_k - i B_k: about R^2 multiply-adds instead of 4 R^2. emit(k, re, im) takes the outputs.
+template <int R, class F>
+__device__ __forceinline__ void dft_small(const float (&xr)[R], const float (&xi)[R], const float (&wr)[R], const float (&wi)[R], F &&emit)
+{
+    constexpr int H = (R - 1) / 2;
+    constexpr bool EVEN = (R % 2) == 0;
+    float sr[H > 0 ? H : 1], si[H > 0 ? H : 1], dr[H > 0 ? H : 1], di[H > 0 ? H : 1];
+#pragma unroll
+    for (int j = 1; j <= H; j++) {
+        sr[j - 1] = xr[j] + xr[R - j]; si[j - 1] = xi[j] + xi[R - j];
+        dr[j - 1] = xr[j] - xr[R - j]; di[j - 1] = xi[j] - xi[R - j];
+    }
+    {
+        float re = xr[0], im = xi[0];
+        if (EVEN) { re += xr[R / 2]; im += xi[R / 2]; }
+#pragma unroll
+        for (int j = 0; j < H; j++) { re += sr[j]; im += si[j]; }
+        emit(0, re, im);
+    }
+#pragma unroll
+    for (int k = 1; k <= H; k++) {
+        float ar = xr[0], ai = xi[0], br = 0.0f, bi = 0.0f;
+        if (EVEN) { if (k & 1) { ar -= xr[R / 2]; ai -= xi[R / 2]; } else { ar += xr[R / 2]; ai += xi[R / 2]; } }
+#pragma unroll
+        for (int j = 1; j <= H; j++) {
+            const int m = (j * k) % R;
+            ar = fmaf(sr[j - 1], wr[m], ar); ai = fmaf(si[j - 1], wr[m], ai);
+            br = fmaf(dr[j - 1], wi[m], br); bi = fmaf(di[j - 1], wi[m], bi);
+        }
+        emit(k, ar - bi, ai + br);
+        emit(R - k, ar + bi, ai - br);
+    }
+    if (EVEN) {
+        float re = xr[0], im = xi[0];
+        if ((R / 2) & 1) { re -= xr[R / 2]; im -= xi[R / 2]; } else { re += xr[R / 2]; im += xi[R / 2]; }
+#pragma unroll
+        for (int j = 1; j <= H; j++) { if (j & 1) { re -= sr[j - 1]; im -= si[j - 1]; } else { re += sr[j - 1]; im += si[j - 1]; } }
+        emit(R / 2, re, im);
     }
 }
 // pass 1 with N1 = R: b[k1 N2 + n2] = W_N^(n2 k1) sum_n1 a[N2 n1 + n2] W_R^(n1 k1)
@@ -356,18 +413,10 @@ __device__ __forceinline__ void dft_pass1_r(const float2 *a, float2 *b, const fl
 #pragma unroll
         for (int n1 = 0; n1 < R; n1++) { const float2 v = x[n1 * N2]; xr[n1] = v.x; xi[n1] = v.y; }
         float2 *o = b + line * stride + n2;
-#pragma unroll
-        for (int k1 = 0; k1 < R; k1++) {
-            float re = xr[0], im = xi[0];
-#pragma unroll
-            for (int n1 = 1; n1 < R; n1++) {
-                const int m = (n1 * k1) % R;
-                re = fmaf(xr[n1], wr[m], fmaf(-xi[n1], wi[m], re));
-                im = fmaf(xr[n1], wi[m], fmaf(xi[n1], wr[m], im));
-            }
+        dft_small<R>(xr, xi, wr, wi, [&](const int k1, const float re, const float im) {
             const float2 t = W[n2 * k1]; const float ty = sgn * t.y;
             o[k1 * N2] = make_float2(re * t.x - im * ty, re * ty + im * t.x);
-        }
+        });
     }
 }
 // pass 2 with N2 = R: a[k1 + N1 k2] = sum_n2 b[k1 N2 + n2] W_R^(n2 k2)
@@ -384,17 +433,7 @@ __device__ __forceinline__ void dft_pass2_r(float2 *a, const float2 *b, const fl
 #pragma unroll
         for (int n2 = 0; n2 < R; n2++) { const float2 v = x[n2]; xr[n2] = v.x; xi[n2] = v.y; }
         float2 *o = a + line * stride + k1;
-#pragma unroll
-        for (int k2 = 0; k2 < R; k2++) {
-            float re = xr[0], im = xi[0];
-#pragma unroll
-            for (int n2 = 1; n2 < R; n2++) {
-                const int m = (n2 * k2) % R;
-                re = fmaf(xr[n2], wr[m], fmaf(-xi[n2], wi[m], re));
-                im = fmaf(xr[n2], wi[m], fmaf(xi[n2], wr[m], im));
-            }
-            o[N1 * k2] = make_float2(re, im);
-        }
+        dft_small<R>(xr, xi, wr, wi, [&](const int k2, const float re, const float im) { o[N1 * k2] = make_float2(re, im); });
     }
 }
 #define MDX_DFT_CASES(F, ...) \
@@ -424,21 +463,27 @@ __global__ __launch_bounds__(256) void k_pme_fft(FftArgs A)
     if (MODE == 0 || MODE == 4) {
         const int nlines = A.K1 * A.K2, L0 = blockIdx.x * nl;
         if (MODE == 0) {
-            for (int idx = threadIdx.x; idx < nl * N; idx += blockDim.x) {
-                const int l = idx / N, n = idx - l * N;
-                float q = 0.0f;
-                if (L0 + l < nlines) { q = A.grid_in[(size_t)(L0 + l) * N + n]; A.grid_in[(size_t)(L0 + l) * N + n] = 0.0f; }
-                a[l * stride + n] = make_float2(q, 0.0f);
-            }
+            // (the nl lines are contiguous in the real grid)
+            float *src = A.grid_in + (size_t)L0 * N;
+            const int nvalid = min(nl, nlines - L0) * N;
+            copy_batched<6, float>(nl * N, [&](const int idx) { return idx < nvalid ? src[idx] : 0.0f; },
+                                   [&](const int idx, const float q) {
+                                       const int l = idx / N, n = idx - l * N;
+                                       if (idx < nvalid) src[idx] = 0.0f;
+                                       a[l * stride + n] = make_float2(q, 0.0f);
+                                   });
         } else {
-            for (int idx = threadIdx.x; idx < nl * K0c; idx += blockDim.x) {
-                // (transposed layout: consecutive threads take consecutive lines, nl x 8 bytes contiguous per k_x)
-                const int l = A.tr ? idx % nl : idx / K0c, k = A.tr ? idx / nl : idx - l * K0c;
-                float2 v = make_float2(0.0f, 0.0f);
-                if (L0 + l < nlines) v = A.tr ? A.cgrid[(size_t)k * nlines + L0 + l] : A.cgrid[(size_t)(L0 + l) * K0c + k];
-                a[l * stride + k] = v;
-                if (k > 0 && N - k >= K0c) a[l * stride + N - k] = make_float2(v.x, -v.y);
-            }
+            // (transposed layout: consecutive threads take consecutive lines, nl x 8 bytes contiguous per k_x)
+            copy_batched<4, float2>(nl * K0c, [&](const int idx) {
+                                        const int l = A.tr ? idx % nl : idx / K0c, k = A.tr ? idx / nl : idx - l * K0c;
+                                        if (L0 + l >= nlines) return make_float2(0.0f, 0.0f);
+                                        return A.tr ? A.cgrid[(size_t)k * nlines + L0 + l] : A.cgrid[(size_t)(L0 + l) * K0c + k];
+                                    },
+                                    [&](const int idx, const float2 v) {
+                                        const int l = A.tr ? idx % nl : idx / K0c, k = A.tr ? idx / nl : idx - l * K0c;
+                                        a[l * stride + k] = v;
+                                        if (k > 0 && N - k >= K0c) a[l * stride + N - k] = make_float2(v.x, -v.y);
+                                    });
         }
         __syncthreads();
         dft_lines_fast(a, b, Wl, nl, N, A.N1, A.N2, MODE == 4);
@@ -463,10 +508,11 @@ __global__ __launch_bounds__(256) void k_pme_fft(FftArgs A)
     const int other = blockIdx.x / nchunk, kx0 = (blockIdx.x - other * nchunk) * nl;
     const size_t base = (MODE == 2) ? (size_t)other * K0c : (size_t)other * A.K1 * K0c;       // z pass: other = y; y pass: other = z
     const size_t estride = (MODE == 2) ? (size_t)A.K1 * K0c : (size_t)K0c;
-    for (int idx = threadIdx.x; idx < nl * N; idx += blockDim.x) {
-        const int n = idx / nl, c = idx - n * nl;
-        a[c * stride + n] = (kx0 + c < K0c) ? A.cgrid[base + (size_t)n * estride + kx0 + c] : make_float2(0.0f, 0.0f);
-    }
+    copy_batched<3, float2>(nl * N, [&](const int idx) {
+                                const int n = idx / nl, c = idx - n * nl;
+                                return (kx0 + c < K0c) ? A.cgrid[base + (size_t)n * estride + kx0 + c] : make_float2(0.0f, 0.0f);
+                            },
+                            [&](const int idx, const float2 v) { const int n = idx / nl; a[(idx - n * nl) * stride + n] = v; });
     __syncthreads();
     dft_lines_fast(a, b, Wl, nl, N, A.N1, A.N2, MODE == 3);
     if (MODE == 2) {
@@ -565,20 +611,12 @@ __device__ __forceinline__ void yz_pass(float2 *P, const float2 *W, int N, int n
                 xr[j] = v.x * t.x - v.y * ty; xi[j] = v.x * ty + v.y * t.x;
             } else { xr[j] = v.x; xi[j] = v.y; }
         }
-#pragma unroll
-        for (int k = 0; k < R; k++) {
-            float re = xr[0], im = xi[0];
-#pragma unroll
-            for (int j = 1; j < R; j++) {
-                const int m = (j * k) % R;
-                re = fmaf(xr[j], wr[m], fmaf(-xi[j], wi[m], re));
-                im = fmaf(xr[j], wi[m], fmaf(xi[j], wr[m], im));
-            }
+        dft_small<R>(xr, xi, wr, wi, [&](const int k, const float re, const float im) {
             if (TW == 1 && k > 0) {
                 const float2 t = W[sub * k]; const float ty = sgn * t.y;
                 p[k * rs] = make_float2(re * t.x - im * ty, re * ty + im * t.x);
             } else p[k * rs] = make_float2(re, im);
-        }
+        });
     }
 }
 template <int R> __device__ __forceinline__ void yz_pass_tw_out(float2 *P, const float2 *W, int N, int nl, int ls, int nsub, int ss, int rs, float sgn) { yz_pass<R, 1>(P, W, N, nl, ls, nsub, ss, rs, sgn); }
@@ -611,10 +649,8 @@ __global__ __launch_bounds__(MDX_YZ_THREADS) __attribute__((amdgpu_waves_per_eu(
     for (int j = threadIdx.x; j < K2; j += blockDim.x) Wz[j] = A.Wz[j];
     const int k0 = blockIdx.x;
     float2 *plane = A.cgrid + (size_t)k0 * K1 * K2;
-    for (int idx = threadIdx.x; idx < K1 * K2; idx += blockDim.x) {
-        const int z = idx / K1, y = idx - z * K1;
-        P[z * ps + y] = plane[idx];
-    }
+    copy_batched<9, float2>(K1 * K2, [&](const int idx) { return plane[idx]; },
+                            [&](const int idx, const float2 v) { const int z = idx / K1; P[z * ps + idx - z * K1] = v; });
     __syncthreads();
     yz_lines<false>(P, Wy, K1, A.N1y, A.N2y, K2, ps, 1);
     yz_lines<false>(P, Wz, K2, A.N1z, A.N2z, K1, 1, ps);
@@ -878,6 +914,8 @@ int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done)
             fft_split(K1, Y.N1y, Y.N2y); fft_split(K2, Y.N1z, Y.N2z);
             Y.d = s->d; Y.dw = s->d; Y.bm0 = s->bmod[0]; Y.bm1 = s->bmod[1]; Y.bm2 = s->bmod[2]; Y.beta = s->beta;
             const size_t ldsy = sizeof(float2) * ((size_t)K1 + K2 + (size_t)K2 * (K1 + 1));
+            // (512 threads: a workgroup does not fit beside the twelve waves of the energy kernel, so on energy steps it runs
+            // behind that kernel; 256 threads fit and run beside it, and the step is 1.3 % slower, 1030 against 1043 ns/day)
             if (energy) hipLaunchKernelGGL(k_pme_fft_yz<true>, dim3(F.K0c), dim3(MDX_YZ_THREADS), ldsy, s->st_pme, Y);
             else hipLaunchKernelGGL(k_pme_fft_yz<false>, dim3(F.K0c), dim3(MDX_YZ_THREADS), ldsy, s->st_pme, Y);
         } else {
