@@ -342,6 +342,11 @@ extern "C" int mdx_set_settles(mdx_system *s, int n, const int *idx, float doh, 
     for (int a = 0; a < n; a++) t[a] = make_int4(idx[3 * a], idx[3 * a + 1], idx[3 * a + 2], 0);
     s->nsettle = n; s->nsettle_cap = n; s->settle_doh = doh; s->settle_dhh = dhh;
     s->h_settle.assign(idx, idx + 3 * (size_t)n); s->fused_plan = 0;
+    // waters listed one after the other (O H H of water w at first + 3 w ...), as a solvated system's topology has them: the
+    // fused update then computes a water's atom indices instead of loading them (one dependent memory round trip fewer)
+    s->settle_first = n > 0 ? idx[0] : -1;
+    for (int a = 0; a < n && s->settle_first >= 0; a++)
+        for (int k = 0; k < 3; k++) if (idx[3 * a + k] != idx[0] + 3 * a + k) s->settle_first = -1;
     return dev_upload(s, &s->settle_idx, t);
 }
 

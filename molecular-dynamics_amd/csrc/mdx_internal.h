@@ -209,6 +209,7 @@ struct mdx_system {
     // constraints
     int nsettle_cap = 0;          // settles set up (domain decomposition activates the first nsettle of them)
     int nsettle = 0; int4 *settle_idx = nullptr; float settle_doh = 0, settle_dhh = 0;
+    int settle_first = -1;        // first atom of the first water when the waters' atoms are consecutive in the order listed, else -1
     int ncons = 0; int ncomp = 0; int ncomp_small = 0;   // components are sorted by size; the first ncomp_small have <= 4 constraints
     int2 *cons_ij = nullptr; float *cons_len = nullptr; int *comp_start = nullptr;  // constraints sorted by component
     int lincs_order = 4, lincs_iter = 1;

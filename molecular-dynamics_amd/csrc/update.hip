@@ -305,6 +305,7 @@ struct FusedArgs {
     const int *comp_atom_start; const int *comp_atoms;
     const int2 *comp_local;     // per constraint: positions of its two atoms in the component's atom list
     int write_sorted; const int *shift_s; float4 *xq_s;
+    int settle_first;           // >= 0: atom `role` of water w is settle_first + 3 w + role (no index load)
 };
 __device__ __forceinline__ void d_sorted_write(const FusedArgs &A, const int g, const float4 p)
 {
@@ -429,8 +430,8 @@ __global__ __launch_bounds__(128) void k_update_fused(FusedArgs A)
         int i = 0, g = 0;
         float4 xi = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vi = xi, xpo = xi;
         if (valid) {
-            const int4 a = C.settle_idx[w];
-            i = role == 0 ? a.x : (role == 1 ? a.y : a.z);
+            if (A.settle_first >= 0) i = A.settle_first + 3 * w + role;
+            else { const int4 a = C.settle_idx[w]; i = role == 0 ? a.x : (role == 1 ? a.y : a.z); }
             xi = C.x[i]; vi = C.v[i];
             d_leap(A.L, i, xi, vi, xpo, g);
         }
@@ -828,6 +829,7 @@ int mdx_launch_update_fused(mdx_system *s, bool do_tc, bool do_pr, bool write_so
     A.nfree = s->nfree; A.nbfree = (s->nfree + 127) / 128; A.free_atoms = s->free_atoms;
     A.comp_atom_start = s->comp_atom_start; A.comp_atoms = s->comp_atoms; A.comp_local = (const int2 *)s->comp_local;
     A.write_sorted = write_sorted ? 1 : 0; A.shift_s = s->shift_s; A.xq_s = s->xq_s;
+    A.settle_first = s->settle_first;
     const int nb16 = (s->ncomp - s->ncomp_small + MDX_FUSED_LARGE_THREADS - 1) / MDX_FUSED_LARGE_THREADS;
     A.nbw3 = (s->nsettle + 41) / 42;
     const int nblocks = A.nbw3 + A.C.nb4 + A.nbfree + nb16;
