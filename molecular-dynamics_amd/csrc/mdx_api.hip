@@ -415,20 +415,23 @@ extern "C" int mdx_set_nonbonded(mdx_system *s, float rc, float rlist, float bet
         const double z = sqrt(w);
         return (erf(z) / z - c * exp(-w)) / w;
     };
-    for (int k = 0; k < MDX_GTAB_N; k++) {
-        const double g0 = g(wmax * k / MDX_GTAB_N), g1 = g(wmax * (k + 1) / MDX_GTAB_N);
-        tab[k] = make_float2((float)g0, (float)(g1 - g0));
-    }
     auto h = [](double w) {
         const double c = 1.1283791670955126;
         if (w < 0.05) return c * (1.0 + w * (-1.0 / 3.0 + w * (0.1 + w * (-1.0 / 42.0 + w * (1.0 / 216.0 - w / 1320.0)))));
         const double z = sqrt(w);
         return erf(z) / z;
     };
+    // energy kernel: beta^3 g and beta h per interval as lines c0 + c1 r^2 through the end points, written in r^2 itself
+    // (erfc(beta r)/r = 1/r - beta h, so an energy step evaluates no exponential and takes no fractional part)
     std::vector<float4> tab4(MDX_GTAB_N);
-    for (int k = 0; k < MDX_GTAB_N; k++) {
-        const double h0 = h(wmax * k / MDX_GTAB_N), h1 = h(wmax * (k + 1) / MDX_GTAB_N);
-        tab4[k] = make_float4(tab[k].x, tab[k].y, (float)h0, (float)(h1 - h0));
+    {
+        const double b3 = (double)beta * beta * beta, scale = (double)MDX_GTAB_N / ((double)rc * rc);
+        for (int k = 0; k < MDX_GTAB_N; k++) {
+            const double g0 = g(wmax * k / MDX_GTAB_N), g1 = g(wmax * (k + 1) / MDX_GTAB_N);
+            const double h0 = h(wmax * k / MDX_GTAB_N), h1 = h(wmax * (k + 1) / MDX_GTAB_N);
+            const double cg = b3 * (g1 - g0), ch = (double)beta * (h1 - h0);
+            tab4[k] = make_float4((float)(b3 * g0 - cg * k), (float)(cg * scale), (float)(beta * h0 - ch * k), (float)(ch * scale));
+        }
     }
     if (!s->htab) MDX_CHECK(s, hipMalloc((void **)&s->htab, sizeof(float4) * MDX_GTAB_N));
     MDX_CHECK(s, hipMemcpy(s->htab, tab4.data(), sizeof(float4) * MDX_GTAB_N, hipMemcpyHostToDevice));

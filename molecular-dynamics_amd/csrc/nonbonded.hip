@@ -109,6 +109,12 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
     static_assert(TAB == 0 || TAB == (ENERGY ? 2 : 1), "force kernels take the float2 table, energy kernels the float4 table");
     constexpr bool ILDS = TAB != 0;
     constexpr bool XM = !ENERGY && TAB == 1;      // execution-masked plain tile (see the tile below)
+    constexpr bool XME = ENERGY && TAB == 2 && !WGT;      // ... of the energy kernel
+    // Virial of the energy kernel from position-force sums instead of nine instructions per pair: within a work unit
+    // sum_pairs (x_i - x_j) (x) f_ij = sum_i (x_i - O) (x) F_i + sum_j (x_j - O) (x) F_j for any origin O (the unit's forces
+    // add up to zero), and F_i (per unit) and F_j (per entry) are formed for the force accumulation anyway. Not with pair
+    // weights (a decomposed run), which differ from pair to pair.
+    constexpr bool PFV = ENERGY && !WGT;
     long long t_start = 0, w_start = 0; int n_units = 0, n_entries = 0, n_tested = 0, n_eval = 0;
     if (TIMED) { t_start = clock64(); w_start = wall_clock64(); }
     const int lane = threadIdx.x & 63;
@@ -120,9 +126,10 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
     unsigned int npair = 0, nlj = 0;           // wave-uniform: lane masks counted on the scalar unit
     const bool do_pairs = A.do_pairs != 0, do_excl = A.do_excl != 0;
     float vxx = 0.0f, vxy = 0.0f, vxz = 0.0f, vyy = 0.0f, vyz = 0.0f, vzz = 0.0f;
-    const float rc2 = A.rc2, beta = A.beta;
+    float pvj[3] = { 0.0f, 0.0f, 0.0f }, pvi[3] = { 0.0f, 0.0f, 0.0f };       // PFV: row a of the tensor; the column is the force component the lane holds
+    const float rc2 = A.rc2, beta = A.beta, inv_rc2 = 1.0f / A.rc2;
     float scale_v = A.tab_scale;
-    if (XM) asm volatile("v_mov_b32 %0, %1" : "=v"(scale_v) : "s"(A.tab_scale));    // (an operand from a scalar register halves the instruction's rate)
+    if (XM || XME) asm volatile("v_mov_b32 %0, %1" : "=v"(scale_v) : "s"(A.tab_scale));    // (an operand from a scalar register halves the instruction's rate)
     const float beta2 = beta * beta, beta3 = beta2 * beta;
     const float nb2l2e = -beta2 * 1.4426950408889634f;
     // Work units are sorted by descending cost. The expensive ones are dealt statically in snake order
@@ -170,6 +177,9 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
         if (TIMED) { n_units++; n_entries += count; }
         const bool is_central = shift_idx == A.central;
         const float4 S = A.shiftvec[shift_idx];
+        // origin of the unit's position-force sums: the first atom of the super-cluster, shifted (wave-uniform)
+        float4 O4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (PFV) { O4 = A.xq_s[sci * 64]; O4.x -= S.x; O4.y -= S.y; O4.z -= S.z; }
         NbEntry myent; myent.cj = 0; myent.mask = 0;
         if (lane < count) myent = A.cj[e0 + lane];
 #pragma unroll 1
@@ -274,6 +284,45 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                     }
                     return;
                 }
+                if (XME && !GENERAL) {
+                    // Plain tile of the energy kernel, written like the force kernel's: under the execution mask, the table
+                    // (16-byte entries: lines of beta^3 g and beta h in r^2) addressed from the mantissa of r^2 scale + 2^19.
+                    const bool in_rc = r2 < rc2;
+                    if (__builtin_amdgcn_ballot_w64(in_rc) == 0ull) return;
+                    did = true;
+                    const float2 li = myilj[c * 8 + ti];
+                    if (COUNT) {
+                        // statistics: pairs of real atoms (a filler carries a negative half-sigma) inside the cutoff
+                        const bool counted = in_rc && li.x >= 0.0f && lj.x >= 0.0f;
+                        npair += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(counted));
+                        nlj += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(counted && li.y * lj.y != 0.0f));
+                    }
+                    if (in_rc) {
+                        const float rinv = __frsqrt_rn(r2);
+                        const float rinv2 = rinv * rinv;
+                        const float u = fmaf(r2, scale_v, 524288.0f - 0.03125f);
+                        const float4 te = *(const float4 *)((const char *)gtab + (__float_as_uint(u) & 0xFFF0u));
+                        const float sg = li.x + lj.x;
+                        const float e4 = li.y * lj.y;          // (no copies of other domains' atoms here: both factors >= 0)
+                        const float sg2 = sg * sg;
+                        const float s2 = sg2 * rinv2;
+                        const float s6 = s2 * s2 * s2;
+                        const float t6 = e4 * s6;
+                        float fs = t6 * fmaf(12.0f, s6, -6.0f);
+                        const float qq = qi[c] * pj.w;
+                        fs = fmaf(qq, rinv, fs) * rinv2;
+                        fs = fmaf(-qq, fmaf(r2, te.y, te.x), fs);
+                        // erfc(beta r)/r - shift = 1/r - beta h - shift
+                        ecoul = fmaf(qq, (rinv - fmaf(r2, te.w, te.z)) - A.c_rf_shift, ecoul);
+                        const float c2 = sg2 * inv_rc2;
+                        const float c6 = c2 * c2 * c2;
+                        elj = fmaf(t6, s6 - 1.0f, elj);
+                        elj = fmaf(-e4 * c6, c6 - 1.0f, elj);
+                        fix[c] = fmaf(dx, fs, fix[c]); fiy[c] = fmaf(dy, fs, fiy[c]); fiz[c] = fmaf(dz, fs, fiz[c]);
+                        fjx = fmaf(-dx, fs, fjx); fjy = fmaf(-dy, fs, fjy); fjz = fmaf(-dz, fs, fjz);
+                    }
+                    return;
+                }
                 bool within = r2 < rc2;
                 if (GENERAL) within = within && ((live >> c) & 1u);
                 if (TIMED) n_tested++;
@@ -296,15 +345,14 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                 float erfc_br = 0.0f, e_ex = 0.0f;
                 if (ENERGY && TAB == 2) {
                     // g and h(w) = erf(z)/z from one LDS table entry: erfc(beta r)/r = 1/r - beta h, no exponential
-                    const float t = r2 * A.tab_scale;
-                    const float4 te = ((const float4 *)gtab)[(unsigned)t & (MDX_GTAB_N - 1)];
-                    const float fr = __builtin_amdgcn_fractf(t);
-                    const float g = fmaf(fr, te.y, te.x), h = fmaf(fr, te.w, te.z);
+                    // (entry: the lines of beta^3 g and beta h in r^2 on the interval)
+                    const float4 te = ((const float4 *)gtab)[(unsigned)(r2 * A.tab_scale) & (MDX_GTAB_N - 1)];
+                    const float g = fmaf(r2, te.y, te.x), h = fmaf(r2, te.w, te.z);
                     fs = fmaf(qq, rinv, fs) * rinv2;
                     if (GENERAL && slot) fs = listed ? fs : 0.0f;
-                    fs = fmaf(-qq * beta3, g, fs);
-                    erfc_br = fmaf(-beta * h, r2 * rinv, 1.0f);        // erfc(beta r) = 1 - beta r h
-                    e_ex = -qq * beta * h;
+                    fs = fmaf(-qq, g, fs);
+                    erfc_br = fmaf(-h, r2 * rinv, 1.0f);        // erfc(beta r) = 1 - beta r h
+                    e_ex = -qq * h;
                 } else if (ENERGY) {
                     const float br = beta * r2 * rinv;
                     const float ex2 = __builtin_amdgcn_exp2f(nb2l2e * r2);
@@ -364,7 +412,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                         const float wx = wgt * fx, wy = wgt * fy, wz = wgt * fz;
                         vxx = fmaf(dx, wx, vxx); vxy = fmaf(dx, wy, vxy); vxz = fmaf(dx, wz, vxz);
                         vyy = fmaf(dy, wy, vyy); vyz = fmaf(dy, wz, vyz); vzz = fmaf(dz, wz, vzz);
-                    } else {
+                    } else if (!PFV) {
                         vxx = fmaf(dx, fx, vxx); vxy = fmaf(dx, fy, vxy); vxz = fmaf(dx, fz, vxz);
                         vyy = fmaf(dy, fy, vyy); vyz = fmaf(dy, fz, vyz); vzz = fmaf(dz, fz, vzz);
                     }
@@ -389,6 +437,11 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
             // (one 24-lane atomic per entry: pairing two entries into one 48-lane atomic costs more VALU instructions in
             // the selects than the second atomic costs now that no wait sits behind it)
             if (did && ti < 3) atomicAdd(at32(A.f_s, (unsigned)(3 * (cj * 8 + tj) + ti)), fj3);
+            if (PFV && did) {
+                // lanes ti < 3 hold component ti of the force on j-atom tj
+                const float fm = ti < 3 ? fj3 : 0.0f;
+                pvj[0] = fmaf(pj.x - O4.x, fm, pvj[0]); pvj[1] = fmaf(pj.y - O4.y, fm, pvj[1]); pvj[2] = fmaf(pj.z - O4.z, fm, pvj[2]);
+            }
         };
         JSet Ja, Jb;
         fetch(Ja, 0);
@@ -411,6 +464,11 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
             float val = (t1 ? z_ : a_) + __shfl_xor(t1 ? a_ : z_, 16, 64);
             val += __shfl_xor(val, 32, 64);
             if (tj < 3) atomicAdd(at32(A.f_s, (unsigned)(3 * ((sci * 8 + c0 + c) * 8 + ti) + tj)), val);
+            if (PFV) {
+                // lanes tj < 3 hold component tj of the force on i-atom ti of cluster c
+                const float fm = tj < 3 ? val : 0.0f;
+                pvi[0] = fmaf(xi[c] - O4.x, fm, pvi[0]); pvi[1] = fmaf(yi[c] - O4.y, fm, pvi[1]); pvi[2] = fmaf(zi[c] - O4.z, fm, pvi[2]);
+            }
         }
         }
         }
@@ -429,8 +487,19 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
     }
     if (ENERGY) {
         elj = wave_sum(elj); ecoul = wave_sum(ecoul); eexcl = wave_sum(eexcl);
-        vxx = wave_sum(vxx); vxy = wave_sum(vxy); vxz = wave_sum(vxz);
-        vyy = wave_sum(vyy); vyz = wave_sum(vyz); vzz = wave_sum(vzz);
+        float v9[9];
+        if (PFV) {
+            // element (a, b): row a of the j-side sums of the lanes that held component b (ti == b), and of the i-side
+            // sums of the lanes with tj == b
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++) v9[3 * a + b] = wave_sum((ti == b ? pvj[a] : 0.0f) + (tj == b ? pvi[a] : 0.0f));
+        } else {
+            vxx = wave_sum(vxx); vxy = wave_sum(vxy); vxz = wave_sum(vxz);
+            vyy = wave_sum(vyy); vyz = wave_sum(vyz); vzz = wave_sum(vzz);
+            v9[0] = vxx; v9[1] = vxy; v9[2] = vxz; v9[3] = vxy; v9[4] = vyy; v9[5] = vyz; v9[6] = vxz; v9[7] = vyz; v9[8] = vzz;
+        }
         const unsigned long long np64 = npair, nl64 = nlj;
         if (lane == 0) {
             // replicated accumulators (folded by the finishing kernel): one replica per wave index mod 64
@@ -443,9 +512,8 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
             atomicAdd(&A.dw->ener_rep[rep][MDX_E_COUL_SR], (double)ecoul);
             atomicAdd(&A.dw->ener_rep[rep][MDX_E_COUL_EXCL], (double)eexcl);
             double *v = A.dw->vir_rep[rep];
-            atomicAdd(&v[0], -0.5 * vxx); atomicAdd(&v[1], -0.5 * vxy); atomicAdd(&v[2], -0.5 * vxz);
-            atomicAdd(&v[3], -0.5 * vxy); atomicAdd(&v[4], -0.5 * vyy); atomicAdd(&v[5], -0.5 * vyz);
-            atomicAdd(&v[6], -0.5 * vxz); atomicAdd(&v[7], -0.5 * vyz); atomicAdd(&v[8], -0.5 * vzz);
+#pragma unroll
+            for (int k = 0; k < 9; k++) atomicAdd(&v[k], -0.5 * (double)v9[k]);
         }
     }
 }
@@ -468,9 +536,10 @@ __device__ __forceinline__ void nb_force_tab(const NbArgs &A)
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_f(NbArgs A) { nb_force_tab<false>(A); }
 // ... with per-wave clocks and tile counters (mdx_debug_wave_times)
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f_timed(NbArgs A) { nb_force_tab<true>(A); }
-// Energy/virial kernel with g and h tabulated (64 KB per CU): no exponential, no erfc polynomial. NI = 4 fits beside the
-// kernels of the PME and bonded streams; COUNT adds the pair statistics (mdx_compute_forces, and steps that ask for them);
-// WGT the pair weights of a decomposed run.
+// Energy/virial kernel with g and h tabulated (64 KB per CU): no exponential, no erfc polynomial. Four i-clusters at a
+// time (two passes over a unit's entries), which fits beside the kernels of the PME and bonded streams: all eight in one
+// pass (158 registers) is faster alone and no faster inside the step (1032-1047 against 1050 ns/day). COUNT adds the pair
+// statistics (mdx_compute_forces, and steps that ask for them); WGT the pair weights of a decomposed run.
 template <int NI, bool WGT, bool COUNT>
 __device__ __forceinline__ void nb_energy_tab(const NbArgs &A)
 {
@@ -484,9 +553,6 @@ __device__ __forceinline__ void nb_energy_tab(const NbArgs &A)
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_ev(NbArgs A) { nb_energy_tab<4, false, false>(A); }
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_ev_count(NbArgs A) { nb_energy_tab<4, false, true>(A); }
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_ev_dd(NbArgs A) { nb_energy_tab<4, true, true>(A); }
-// (one pass over the entries with all eight i-clusters: faster alone, slower inside the step; mdx_debug_set key 2 bit 0x1000000)
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_ev8(NbArgs A) { nb_energy_tab<8, false, false>(A); }
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_ev8_count(NbArgs A) { nb_energy_tab<8, false, true>(A); }
 // Analytic kernels (rational Ewald correction, exp + erfc polynomial in the energy kernel): what a handle without Ewald
 // tables runs, and the cross-check of the tabulated kernels (mdx_debug_set key 2 bit 0x400000).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f_analytic(NbArgs A) { nb_body<false, 0>(A); }
@@ -546,7 +612,6 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
         grid = dim3(256 * 3); block = dim3(256);
     } else if (!energy) kern = s->nb_wave_t ? k_nonbonded_f_timed : k_nonbonded_f;
     else if (s->dd_on) kern = k_nonbonded_ev_dd;
-    else if (s->dbg & 0x1000000) kern = s->count_pairs ? k_nonbonded_ev8_count : k_nonbonded_ev8;
     else kern = s->count_pairs ? k_nonbonded_ev_count : k_nonbonded_ev;
     hipExtLaunchKernelGGL(kern, grid, block, 0, s->stream, ev_a, ev_b, 0, A);
     MDX_CHECK(s, hipGetLastError());
