@@ -101,7 +101,8 @@ extern "C" mdx_system *mdx_create(int device, int natoms)
               hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_pme, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_bond, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
-              hipEventCreateWithFlags(&s->ev_spread, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
+              hipEventCreateWithFlags(&s->ev_spread, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess &&
+              hipEventCreateWithFlags(&s->ev_prune, hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
     s->own_streams[0] = s->stream; s->own_streams[1] = s->st_pme; s->own_streams[2] = s->st_bond;
     // MDX_STREAMS=1: every kernel of the handle on one stream (diagnostic; three streams are the default)
     if (const char *e = getenv("MDX_STREAMS")) if (atoi(e) == 1 && ok) (void)mdx_set_stream_mode(s, 1);
@@ -166,6 +167,7 @@ extern "C" void mdx_destroy(mdx_system *s)
     if (s->ev_pme) (void)hipEventDestroy(s->ev_pme);
     if (s->ev_bond) (void)hipEventDestroy(s->ev_bond);
     if (s->ev_spread) (void)hipEventDestroy(s->ev_spread);
+    if (s->ev_prune) (void)hipEventDestroy(s->ev_prune);
     for (hipStream_t st : s->own_streams) if (st) (void)hipStreamDestroy(st);
     delete s;
 }
@@ -732,6 +734,15 @@ int mdx_fork(mdx_system *s)
     MDX_CHECK(s, hipStreamWaitEvent(s->st_bond, s->ev_fork, 0));
     return MDX_OK;
 }
+// The main stream waits for a pruning launch that is still unaccounted for: ahead of every kernel that rewrites the
+// sorted coordinates the pruning kernel reads, and thereby ahead of the first nonbonded launch on the pruned list.
+int mdx_wait_prune(mdx_system *s)
+{
+    if (!s->prune_pending) return MDX_OK;
+    MDX_CHECK(s, hipStreamWaitEvent(s->stream, s->ev_prune, 0));
+    s->prune_pending = false;
+    return MDX_OK;
+}
 int mdx_join(mdx_system *s)
 {
     if (!s->pme_signalled) MDX_CHECK(s, hipEventRecord(s->ev_pme, s->st_pme));
@@ -898,7 +909,7 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
     const bool do_pc = s->pcoupl != 0 && (step % s->nstpcouple == 0);
     const bool need_vir = do_ener || do_pc;
     const bool tc_apply = s->ntc > 0 && (step % s->nsttcouple == 0);
-    bool pruned = false;
+    bool pruned = false, do_prune = false;
     if (phase != 2) {
         if (s->first_step && s->ntc > 0 && !(s->dd_on && !s->dd_own_tcouple)) {
             if ((rc = mdx_launch_clear(s, false, true, false))) return rc;
@@ -932,18 +943,24 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
             const bool log_now = (step % s->pull_nstout == 0);
             if ((rc = mdx_launch_pull(s, log_now, need_vir))) return rc;
         }
-        // Rolling prune of the pair list: beside this step's nonbonded kernel (which still reads the list of the last
-        // prune, or on a search step the outer list itself) the bonded stream derives the list of the coming steps
-        // from this step's coordinates. The join below orders it ahead of the next nonbonded launch.
-        if (s->nstprune > 0 && phase == 0 && !s->dd_on && s->steps_since_search % s->nstprune == 0 &&
-            s->steps_since_search + 1 < s->nstlist) {
-            if ((rc = mdx_launch_prune(s, s->st_bond))) return rc;
-            pruned = true;
-        }
+        // Rolling prune of the pair list (launched below, behind the join's marker on the bonded stream)
+        do_prune = s->nstprune > 0 && phase == 0 && !s->dd_on && s->steps_since_search % s->nstprune == 0 &&
+                   s->steps_since_search + 1 < s->nstlist;
         if (phase == 1) return MDX_OK;
     }
     if (phase == 2) if ((rc = mdx_launch_pme(s, need_vir && s->dd_mesh_energy, true))) return rc;
     if ((rc = mdx_join(s))) return rc;
+    if (do_prune) {
+        // Beside this step's nonbonded kernel (which still reads the list of the last prune, or on a search step the outer
+        // list itself) the bonded stream derives the list of the coming steps from this step's sorted coordinates. The
+        // launch stands behind the marker the join has just recorded on that stream, so the update does not wait for it:
+        // it has to be complete when the sorted coordinates are next overwritten (mdx_wait_prune ahead of the fused update
+        // or the next prepare kernel), which on a step that also accumulates energies is the next step.
+        if ((rc = mdx_launch_prune(s, s->st_bond))) return rc;
+        MDX_CHECK(s, hipEventRecord(s->ev_prune, s->st_bond));
+        s->prune_pending = true;
+        pruned = true;
+    }
     // The PME and bonded kernels of the next step read only the new positions (the spread goes through the
     // sort permutation): when that step neither rebuilds the list nor accumulates energies they are
     // released here, ahead of the thermostat kernels and the coordinate sort, instead of by the prepare kernel.
@@ -958,6 +975,7 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
         const bool fused = phase == 0 && !need_vir && !s->dd_on && s->fused_update && mdx_fused_plan(s) == 1;
         if (fused) {
             prepared = more && !search_next;
+            if (prepared) if ((rc = mdx_wait_prune(s))) return rc;        // the launch rewrites the sorted coordinates
             if ((rc = mdx_launch_update_fused(s, tc_apply, s->pcoupl == 2, prepared, fork_now && prepared))) return rc;
             if (fork_now && prepared) forked_early = true;
         } else if ((rc = mdx_launch_update(s, tc_apply, s->pcoupl == 2, need_vir))) return rc;

@@ -131,7 +131,8 @@ struct mdx_system {
     hipStream_t stream = nullptr;      // main stream: search, nonbonded, update
     hipStream_t st_pme = nullptr;      // PME chain (spread, FFTs, solve, gather) overlaps the nonbonded kernel
     hipStream_t st_bond = nullptr;     // bonded, restraint, exclusion and pull kernels
-    hipEvent_t ev_fork = nullptr, ev_pme = nullptr, ev_bond = nullptr, ev_spread = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_pme = nullptr, ev_bond = nullptr, ev_spread = nullptr, ev_prune = nullptr;
+    bool prune_pending = false;        // a pruning launch on the bonded stream has not been waited for yet (mdx_wait_prune)
     float *f_pme = nullptr;            // 3N mesh forces (plain stores, so no race with the atomics on f)
     std::string err;
     int n = 0;                    // atoms
@@ -279,6 +280,7 @@ struct mdx_system {
 int mdx_set_stream_mode(mdx_system *s, int one_stream);
 int mdx_search(mdx_system *s);
 int mdx_launch_prune(mdx_system *s, hipStream_t st);
+int mdx_wait_prune(mdx_system *s);
 int mdx_fork(mdx_system *s);
 int mdx_join(mdx_system *s);
 int mdx_launch_prepare(mdx_system *s, bool fork = false);

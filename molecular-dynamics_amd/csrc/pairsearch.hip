@@ -706,6 +706,7 @@ __global__ void k_prepare(int npad, DevState *__restrict__ d, const float4 *__re
 // recorded by a separate marker costs the main stream several microseconds between two kernels).
 int mdx_launch_prepare(mdx_system *s, bool fork)
 {
+    { const int rc = mdx_wait_prune(s); if (rc) return rc; }
     const int nb = (s->npad + 255) / 256;
     if (fork) {
         hipExtLaunchKernelGGL(k_prepare, dim3(nb), dim3(256), 0, s->stream, nullptr, s->ev_fork, 0, s->npad, s->d,
@@ -746,6 +747,7 @@ static void build_shift_list(mdx_system *s, const double *box)
 
 int mdx_search(mdx_system *s)
 {
+    { const int rc = mdx_wait_prune(s); if (rc) return rc; }       // (a pruning launch still reads the lists rebuilt here)
     // host copy of the box (may lag the device by a few coupling steps; only used for grid counts)
     const double *box = s->h->boxd;
     build_shift_list(s, box);

@@ -914,8 +914,8 @@ int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done)
             fft_split(K1, Y.N1y, Y.N2y); fft_split(K2, Y.N1z, Y.N2z);
             Y.d = s->d; Y.dw = s->d; Y.bm0 = s->bmod[0]; Y.bm1 = s->bmod[1]; Y.bm2 = s->bmod[2]; Y.beta = s->beta;
             const size_t ldsy = sizeof(float2) * ((size_t)K1 + K2 + (size_t)K2 * (K1 + 1));
-            // (512 threads: a workgroup does not fit beside the twelve waves of the energy kernel, so on energy steps it runs
-            // behind that kernel; 256 threads fit and run beside it, and the step is 1.3 % slower, 1030 against 1043 ns/day)
+            // (512 threads: on energy steps the workgroups start only when the energy kernel's waves retire; with 256 threads
+            // they run beside it, twice as long, and the bench is the same within its noise: 1062 against 1059 ns/day)
             if (energy) hipLaunchKernelGGL(k_pme_fft_yz<true>, dim3(F.K0c), dim3(MDX_YZ_THREADS), ldsy, s->st_pme, Y);
             else hipLaunchKernelGGL(k_pme_fft_yz<false>, dim3(F.K0c), dim3(MDX_YZ_THREADS), ldsy, s->st_pme, Y);
         } else {

@@ -7,10 +7,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, mdx
 from mdx import synth, engine as eng
 NAMES = {0: "prepare", 1: "nonbonded", 2: "nonbonded (energy)", 3: "spread", 4: "fft x", 5: "fft y (or y+z fused)", 6: "fft z+solve", 7: "fft y inv",
-         8: "fft x inv", 9: "gather", 10: "bonded", 11: "leapfrog / fused update", 12: "settle", 13: "lincs", 15: "tcouple", 17: "build list"}
+         8: "fft x inv", 9: "gather", 10: "bonded", 11: "leapfrog / fused update", 12: "settle", 13: "lincs", 15: "tcouple", 17: "build list", 18: "prune list"}
 s = synth.pseudo_complex(d=12.5)
 tc = ["Protein", "Non-Protein"]
-e = eng.Engine(s, rc=1.0, dt=0.002, nstlist=20, nstcalcenergy=10, tc_groups=tc, ref_t=[300, 300], tau_t=[0.1, 0.1], nsttcouple=10,
+DUAL = bool(os.environ.get("MDX_DUAL"))       # the bench's dual pair list: outer list 100 steps, pruned every 10 (beside the energy steps)
+CYC = 100 if DUAL else 20
+e = eng.Engine(s, rc=1.0, dt=0.002, nstlist=CYC, nstprune=10 if DUAL else 0, nstcalcenergy=10, tc_groups=tc, ref_t=[300, 300], tau_t=[0.1, 0.1], nsttcouple=10,
                pcoupl=1, tau_p=2.0, ref_p=1.0, compressibility=4.5e-5, nstpcouple=10, dispcorr=2)
 for kv in filter(None, os.environ.get("MDX_DEBUG", "").split(",")):
     e.debug_set(int(kv.split("=")[0]), int(kv.split("=")[1], 0))
@@ -30,9 +32,9 @@ def stamped(nlead, nstamp, ntrail):
     return t
 # align to the step counter: plain steps are those with step % 10 not in (0, 9) and no list rebuild
 st = e.get_step()
-e.step((20 - st % 20) % 20); e.synchronize()      # now step % 20 == 0: next step is search + energy
+e.step((CYC - st % CYC) % CYC); e.synchronize()      # now step % CYC == 0: next step is search + energy
 for lead, label in ((3, "plain step (step %% 20 == 3)"), (10, "energy step (step %% 20 == 10)"), (0, "search + energy step (step %% 20 == 0)")):
-    e.synchronize(); st = e.get_step(); e.step((20 - st % 20) % 20); e.synchronize()
+    e.synchronize(); st = e.get_step(); e.step((CYC - st % CYC) % CYC); e.synchronize()
     t = stamped(lead, 1, 0)
     t0 = t[0][0] if t[1][0] > 0 else min(v for v in t[0] if v < 2**62)
     # a plain step that follows a fused update in the same call has no prepare launch: the prepare stamp is then that of
