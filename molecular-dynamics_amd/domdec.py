@@ -7,23 +7,23 @@ per process. The reference pipeline never decomposes a system (every `gmx mdrun`
 Scheme (see csrc/domdec.hip for the device side):
 
 * The unit cell is cut into px x py x pz bricks in fractional coordinates. A molecule belongs to the brick
-  that holds its first atom. Every pair-list lifetime (`nstlist` steps) all ranks all-gather the home
-  molecules (positions, velocities, ids), re-assign them, and select their halo: molecules of other ranks whose
-  first atom lies within `rlist` + molecule size of the brick (a conservative test per fractional dimension,
-  so it holds in any triclinic cell). Because every rank sees all positions at that moment, it computes the
-  halo of every other rank too and so knows, without further messages, which of its home atoms it has to
-  send where on the following steps, and in which order they arrive.
+  that holds its first atom. Every pair-list lifetime (`nstlist` steps) the partition is renewed by migration
+  (`migrate`): every rank sends the molecules that left its brick to their new owners, then sends every other rank
+  the positions of its home molecules inside that rank's brick grown by `rlist` + molecule size (a conservative
+  test per fractional dimension, so it holds in any triclinic cell): the receiver's halo. The selection doubles as
+  the send list of the following steps; receive counts travel in one all-gather of `world` integers per round.
+  (`migration=False` keeps the first scheme as a cross-check: all ranks all-gather every home molecule and each
+  computes every rank's halo, `plan_exchange`.)
 * Every other step: the positions of those atoms are packed on the device, exchanged point to point
   (one batched send/recv group: `ncclSend`/`ncclRecv` under NCCL) and scattered into the halo slots.
   Forces are not sent back: a pair across a boundary is evaluated by both owners, each keeping its own half.
 * PME: every rank spreads its home charges on a full-size grid, the grids are summed with one all-reduce,
   and every rank solves the whole mesh problem and gathers forces for its home atoms.
-* The thermostat acts per domain (V-rescale with the domain's own degrees of freedom, as a temperature-
-  coupling group would); centre-of-mass motion removal and pressure coupling are off in this mode; energies
-  are not assembled across ranks.
+* Thermostat, barostat (C-rescale or Parrinello-Rahman), dispersion correction and centre-of-mass removal act on the
+  whole system: the domains sum a few scalars per coupling step and apply the same factors (`DecomposedWater`).
 
-The partition arithmetic (`owner_of`, `halo_mask`, `plan_exchange`) is plain torch on whatever device the
-tensors live on, so it is tested on CPU tensors with a two-rank gloo group.
+The partition arithmetic (`owner_of`, `halo_mask`, `plan_exchange`, `migrate`) is plain torch on whatever device the
+tensors live on, so it is tested on CPU tensors with a two-rank gloo group and eight in-process ranks.
 """
 from __future__ import annotations
 
@@ -116,6 +116,49 @@ def plan_exchange(s_first, owner, rank, world, dims, margins):
     return home, recv, send
 
 
+def migrate(tr, x, v, ids, box, dims, margins):
+    """Renew the partition from what each rank holds, without gathering the system anywhere.
+
+    x, v: (n_home, 3, 3) positions and velocities of this rank's home molecules, ids: (n_home,) their global numbers.
+    1. every rank computes the new owner of its home molecules; those that left its brick (within a pair-list
+       lifetime a molecule moves a fraction of a nanometre, so they go to one of the <= 26 bricks around it, but any
+       owner is served) are sent to their owners: x, v and the id in one record of 19 floats;
+    2. every rank then selects, per other rank, its home molecules inside that rank's brick grown by the halo margins
+       and sends their positions: the receiver's halo, grouped by source rank in ascending order, in the order sent;
+       the same selection is the send list of the per-step halo refresh.
+    The receive counts of both rounds travel in one all-gather of `world` integers each. Traffic per rank and lifetime:
+    the emigrants and the halo once, instead of every molecule of the system.
+    Returns x_home, v_home, ids_home, [halo positions (m_src, 3, 3) per source rank], [home slots (k_dst,) per
+    destination rank]."""
+    rank, world = tr.rank, tr.world
+    dev = x.device
+    empty_i = torch.zeros((0,), dtype=torch.int64, device=dev)
+    if world == 1:
+        return x, v, ids, [x[:0]], [empty_i]
+    own = owner_of(fractional(x[:, 0, :].double(), box), dims)
+    rec = torch.cat([x.reshape(-1, 9).float(), v.reshape(-1, 9).float(), ids.to(torch.int32).view(torch.float32).reshape(-1, 1)], 1)
+    out = [torch.nonzero(own == r).flatten() if r != rank else empty_i for r in range(world)]
+    counts = torch.tensor([int(o.numel()) for o in out], dtype=torch.int64, device=dev)
+    table = torch.stack(tr.all_gather(counts))               # table[src][dst]
+    send = [rec[o].contiguous() for o in out]
+    recv = [torch.zeros((int(table[r][rank]) if r != rank else 0, 19), dtype=torch.float32, device=dev) for r in range(world)]
+    tr.exchange(send, recv)
+    rec = torch.cat([rec[own == rank]] + [recv[r] for r in range(world) if r != rank])
+    x_home = rec[:, :9].reshape(-1, 3, 3).to(x.dtype); v_home = rec[:, 9:18].reshape(-1, 3, 3).to(v.dtype)
+    ids_home = rec[:, 18].contiguous().view(torch.int32).to(ids.dtype)
+    # halo: my home molecules that lie in another rank's grown brick
+    s_home = fractional(x_home[:, 0, :].double(), box)
+    mine = torch.full((x_home.shape[0],), rank, dtype=torch.int64, device=dev)
+    sends = [torch.nonzero(halo_mask(s_home, mine, r, dims, margins)).flatten() if r != rank else empty_i for r in range(world)]
+    counts = torch.tensor([int(o.numel()) for o in sends], dtype=torch.int64, device=dev)
+    table = torch.stack(tr.all_gather(counts))
+    pos = x_home.reshape(-1, 9).float()
+    hsend = [pos[o].contiguous() for o in sends]
+    hrecv = [torch.zeros((int(table[r][rank]) if r != rank else 0, 9), dtype=torch.float32, device=dev) for r in range(world)]
+    tr.exchange(hsend, hrecv)
+    return x_home, v_home, ids_home, [h.reshape(-1, 3, 3).to(x.dtype) for h in hrecv], sends
+
+
 # --------------------------------------------------------------------------------------------- transport
 class Transport:
     """Collectives on device tensors; with a gloo group the tensors are staged through the host (tests)."""
@@ -129,7 +172,9 @@ class Transport:
         # device-ordered collectives: RCCL work is ordered against the stream that is current when it is issued, so no host
         # synchronisation is needed around it. MDX_DD_FORCE_COLLECTIVES=1 issues the reductions at world size 1 as well
         # (rehearsal of that ordering on one GPU).
-        self.ordered = dist.is_initialized() and not self.staged
+        # Between real peers the ordered path has not run on hardware yet (the build has one GPU): at world size > 1 the
+        # host-synchronised path is the default and MDX_DD_ORDERED=1 opts in.
+        self.ordered = dist.is_initialized() and not self.staged and (self.world == 1 or os.environ.get("MDX_DD_ORDERED") == "1")
         self.force = self.ordered and bool(os.environ.get("MDX_DD_FORCE_COLLECTIVES"))
 
     def all_gather(self, t: torch.Tensor):
@@ -291,7 +336,8 @@ class DecomposedWater:
                  ref_t: float | None = 300.0, tau_t: float = 0.1, nsttcouple: int = 10, fourierspacing: float = 0.16,
                  rlist: float | None = None, seed: int = 1, group=None, dims=None, nstcalcenergy: int = 0,
                  transport=None, global_coupling: bool = True, nstcomm: int = 0, pcoupl: str | None = None, tau_p: float = 2.0,
-                 ref_p: float = 1.0, compressibility: float = 4.5e-5, nstpcouple: int = 10, dispcorr: int = 0):
+                 ref_p: float = 1.0, compressibility: float = 4.5e-5, nstpcouple: int = 10, dispcorr: int = 0,
+                 migration: bool = True):
         """global_coupling: one V-rescale factor for the whole system from the kinetic energy summed over the domains
         (every domain draws it from the same random stream); False: every domain is its own thermostat group.
         nstcomm > 0: centre-of-mass motion of the whole system removed every nstcomm steps.
@@ -299,12 +345,15 @@ class DecomposedWater:
         steps (needs the shared thermostat seed: every domain draws the same factor); "parrinello-rahman"
         (/root/reference/mdp/production.mdp:36): every domain carries the same box velocity and advances it with the summed
         pressure.
+        migration: the partition is renewed by sending the molecules that left a brick, and the halo, to the ranks that need
+        them (`migrate`); False gathers every molecule on every rank each pair-list lifetime (the cross-check).
         dispcorr: 1 adds the analytic long-range dispersion correction of the whole system (`DispCorr = Ener`) to the
         energies, 2 (`EnerPres`, /root/reference/mdp/production.mdp:44) also to the pressure, the coupled one included: it
         depends on the atom count, the volume and <C6> of the whole system only, so every rank evaluates it itself."""
         from . import engine as eng
         self.tr = transport if transport is not None else Transport(group)
         self.rank, self.world = self.tr.rank, self.tr.world
+        self.migration = bool(migration)
         self.dims = tuple(dims) if dims is not None else rank_grid(self.world)
         assert self.dims[0] * self.dims[1] * self.dims[2] == self.world
         n = sysm.natoms
@@ -379,28 +428,33 @@ class DecomposedWater:
         """Install home + halo from the gathered molecule arrays (M, 3, 3), (M, 3, 3), (M,), owner (M,)."""
         s_first = fractional(x_all[:, 0, :].double(), self.box)
         home, recv, send = plan_exchange(s_first, own, self.rank, self.world, self.dims, self.margins)
-        halo = torch.cat(recv) if self.world > 1 else home[:0]
-        nh, nl = int(home.numel()), int(halo.numel())
+        # position of each gathered molecule in my home block
+        slot_of = torch.full((x_all.shape[0],), -1, device=self.dev, dtype=torch.int64)
+        slot_of[home] = torch.arange(int(home.numel()), device=self.dev)
+        self._install_local(x_all[home], v_all[home], ids_all[home], [x_all[rv] for rv in recv], [slot_of[sd] for sd in send])
+
+    def _install_local(self, x_home, v_home, ids_home, halo_x, send_slots):
+        """Install this rank's home molecules (n, 3, 3), (n, 3, 3), (n,), the halo positions received per source rank
+        (ascending) and, per destination rank, the home slots whose positions it holds as halo (in its slot order)."""
+        halo = torch.cat(halo_x) if self.world > 1 else x_home[:0]
+        nh, nl = int(x_home.shape[0]), int(halo.shape[0])
         if nh + nl > self.cap:
             raise RuntimeError(f"rank {self.rank}: {nh} home + {nl} halo molecules exceed the capacity {self.cap}")
         if nh == 0:
             raise RuntimeError(f"rank {self.rank}: empty domain")
-        order = torch.cat([home, halo])
         x4 = torch.zeros((MOL_ATOMS * (nh + nl), 4), device=self.dev, dtype=torch.float32)
         v4 = torch.zeros_like(x4)
-        x4[:, :3] = x_all[order].reshape(-1, 3)
-        v4[: MOL_ATOMS * nh, :3] = v_all[home].reshape(-1, 3)
-        self.ids_home = ids_all[home].clone()
+        x4[: MOL_ATOMS * nh, :3] = x_home.reshape(-1, 3)
+        x4[MOL_ATOMS * nh:, :3] = halo.reshape(-1, 3)
+        v4[: MOL_ATOMS * nh, :3] = v_home.reshape(-1, 3)
+        self.ids_home = ids_home.clone()
         self.n_home, self.n_halo = nh, nl
         # exchange plan for the steps until the next partition, in atoms
         def atoms_of(mols_local):           # local molecule slots -> atom slots
             return (mols_local[:, None] * MOL_ATOMS + torch.arange(MOL_ATOMS, device=self.dev)[None, :]).reshape(-1)
-        # position of each gathered molecule in my home block
-        slot_of = torch.full((x_all.shape[0],), -1, device=self.dev, dtype=torch.int64)
-        slot_of[home] = torch.arange(nh, device=self.dev)
-        self.send_counts = [int(sd.numel()) * MOL_ATOMS for sd in send]
-        self.recv_counts = [int(rv.numel()) * MOL_ATOMS for rv in recv]
-        self.send_idx = atoms_of(torch.cat([slot_of[sd] for sd in send])).to(torch.int32).contiguous() if self.world > 1 else None
+        self.send_counts = [int(sd.numel()) * MOL_ATOMS for sd in send_slots]
+        self.recv_counts = [int(hx.shape[0]) * MOL_ATOMS for hx in halo_x]
+        self.send_idx = atoms_of(torch.cat(list(send_slots))).to(torch.int32).contiguous() if self.world > 1 else None
         self.send_buf = torch.zeros((sum(self.send_counts), 4), device=self.dev, dtype=torch.float32)
         self.recv_buf = torch.zeros((sum(self.recv_counts), 4), device=self.dev, dtype=torch.float32)
         self._keep = (x4, v4)               # alive until the load kernel has run
@@ -438,9 +492,15 @@ class DecomposedWater:
         if self.pcoupl:
             # the cell has been rescaled since the last partition: halo margins in fractional coordinates follow it
             self.margins = fractional_margins(self.box, self.rlist_margin)
-        x_all, v_all, ids_all = self._gather_all()
-        own = owner_of(fractional(x_all[:, 0, :].double(), self.box), self.dims)
-        self._install(x_all, v_all, ids_all, own)
+        if self.migration and self.world > 1:
+            x, v = self._home_state()
+            xh, vh, ih, halo_x, sends = migrate(self.tr, x, v, self.ids_home, self.box, self.dims, self.margins)
+            halo_x = [h if r != self.rank else xh[:0] for r, h in enumerate(halo_x)]
+            self._install_local(xh, vh, ih, halo_x, sends)
+        else:
+            x_all, v_all, ids_all = self._gather_all()
+            own = owner_of(fractional(x_all[:, 0, :].double(), self.box), self.dims)
+            self._install(x_all, v_all, ids_all, own)
         self.steps_since_partition = 0
 
     def _refresh_halo(self):

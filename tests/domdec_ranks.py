@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 
-def decomposed(world, nst, rest, d):
+def decomposed(world, nst, rest, d, migration=True):
     import mdx
     from mdx import synth, domdec
     hub = domdec.ThreadTransport.Hub(world, exclusive=bool(os.environ.get("MDX_DD_EXCLUSIVE")))
@@ -22,7 +22,8 @@ def decomposed(world, nst, rest, d):
         s = synth.water_box(d=d)
         if rest:
             s.v = np.zeros_like(s.v)
-        dd = domdec.DecomposedWater(s, device=0, rc=1.0, dt=0.002, nstlist=10, ref_t=None, rlist=1.1, transport=transport)
+        dd = domdec.DecomposedWater(s, device=0, rc=1.0, dt=0.002, nstlist=10, ref_t=None, rlist=1.1, transport=transport,
+                                    migration=migration)
         info = dict(dims=dd.dims, home=dd.n_home, halo=dd.n_halo, cap=dd.cap)
         dd.step(nst); dd.synchronize()
         info["list_tiles"] = dd.engine.list_stats()["cluster_pairs"]
@@ -101,8 +102,9 @@ def main(world=2, steps=12, d=7.0):
     import mdx
     from mdx import synth, engine as eng
     res = {"world": world, "steps": steps}
-    for label, nst, rest in (("rest", 1, True), ("traj", steps, False)):
-        o = decomposed(world, nst, rest, d)
+    # ("traj_gather": the partition renewed by gathering every molecule on every rank instead of by migration)
+    for label, nst, rest in (("rest", 1, True), ("traj", steps, False), ("traj_gather", steps, False)):
+        o = decomposed(world, nst, rest, d, migration=label != "traj_gather")
         s = synth.water_box(d=d)
         if rest:
             s.v = np.zeros_like(s.v)
