@@ -478,7 +478,7 @@ def main():
         # HBM bytes per launch of the nonbonded kernel from the PMC passes kept under profiles/
         # (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc runs; not collected live)
         traffic, traffic_src = None, None
-        for rnd in ("r02", "r01"):          # the newest collection that is present
+        for rnd in ("r03", "r02", "r01"):          # the newest collection that is present
             try:
                 with open(os.path.join(ROOT, "profiles", rnd, "nb_pmc_traffic.json")) as f:
                     traffic = float(json.load(f)["hbm_bytes_per_launch"])
