@@ -635,6 +635,8 @@ extern "C" int mdx_set_state_device(mdx_system *s, const void *xd, const void *v
 
 static int sync_and_check(mdx_system *s)
 {
+    // (a pruning launch is the one piece of work that no step joins into the main stream: it ends on the bonded stream)
+    if (s->prune_pending) { MDX_CHECK(s, hipStreamSynchronize(s->st_bond)); s->prune_pending = false; }
     MDX_CHECK(s, hipMemcpyAsync(s->h, s->d, sizeof(DevState), hipMemcpyDeviceToHost, s->stream));
     MDX_CHECK(s, hipStreamSynchronize(s->stream));
     if (s->h->overflow) {
