@@ -233,12 +233,6 @@ __global__ __launch_bounds__(256) void k_unpack3(int n, const float4 *__restrict
 // selects the first entry of the format's small-number table) and a flag for a coordinate that is not finite or does
 // not fit; the host is left with the bit packing (csrc/trajio.cpp, trj_xtc_encode_frame_q).
 // stats: min x y z, max x y z, smallest neighbour difference, flag (set up by k_frame_stats_init).
-__global__ void k_frame_stats_init(int *__restrict__ stats)
-{
-    const int t = threadIdx.x;
-    if (t < 3) stats[t] = INT_MAX; else if (t < 6) stats[t] = INT_MIN; else if (t == 6) stats[t] = INT_MAX; else if (t == 7) stats[t] = 0;
-}
-
 __device__ __forceinline__ bool xtc_round(float xf, float precision, int &l)
 {
     const float lf = __fmul_rn(xf, precision);
@@ -247,33 +241,35 @@ __device__ __forceinline__ bool xtc_round(float xf, float precision, int &l)
     return true;
 }
 
+// The frame's statistics (minima 0-2, maxima 3-5, smallest difference between consecutive atoms 6, a coordinate out of
+// range 7) leave the kernel as one set of eight per workgroup, written with plain stores; the host folds the
+// MDX_FRAME_WGS sets when it takes the frame. (One set updated with atomics needed a launch to initialise it, and the
+// 543 workgroups of a thread-per-atom launch queued up at its eight addresses: 17 us for 139 k atoms against 4.)
+#define MDX_FRAME_WGS 128
 __global__ __launch_bounds__(256) void k_frame_quantize(int n, const float4 *__restrict__ a, float precision, int *__restrict__ out,
                                                         int *__restrict__ stats, const double *__restrict__ boxd,
                                                         double *__restrict__ box_out)
 {
     __shared__ int red[8][4];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 9 && box_out) box_out[i] = boxd[i];
+    if (blockIdx.x == 0 && threadIdx.x < 9 && box_out) box_out[threadIdx.x] = boxd[threadIdx.x];
     int mn[3] = { INT_MAX, INT_MAX, INT_MAX }, mx[3] = { INT_MIN, INT_MIN, INT_MIN }, md = INT_MAX, bad = 0;
-    if (i < n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 p = a[i];
         int l[3];
         const bool ok = xtc_round(p.x, precision, l[0]) & xtc_round(p.y, precision, l[1]) & xtc_round(p.z, precision, l[2]);
-        if (!ok) bad = 1;
-        else {
-            for (int d = 0; d < 3; d++) { mn[d] = l[d]; mx[d] = l[d]; }
-            out[3 * (size_t)i] = l[0]; out[3 * (size_t)i + 1] = l[1]; out[3 * (size_t)i + 2] = l[2];
-            if (i > 0) {
-                const float4 q = a[i - 1];
-                int o[3];
-                if (xtc_round(q.x, precision, o[0]) & xtc_round(q.y, precision, o[1]) & xtc_round(q.z, precision, o[2])) {
-                    const long long diff = llabs((long long)o[0] - l[0]) + llabs((long long)o[1] - l[1]) + llabs((long long)o[2] - l[2]);
-                    md = (int)(diff < (long long)INT_MAX ? diff : (long long)INT_MAX);
-                }
+        if (!ok) { bad = 1; continue; }
+        for (int d = 0; d < 3; d++) { mn[d] = min(mn[d], l[d]); mx[d] = max(mx[d], l[d]); }
+        out[3 * (size_t)i] = l[0]; out[3 * (size_t)i + 1] = l[1]; out[3 * (size_t)i + 2] = l[2];
+        if (i > 0) {
+            const float4 q = a[i - 1];
+            int o[3];
+            if (xtc_round(q.x, precision, o[0]) & xtc_round(q.y, precision, o[1]) & xtc_round(q.z, precision, o[2])) {
+                const long long diff = llabs((long long)o[0] - l[0]) + llabs((long long)o[1] - l[1]) + llabs((long long)o[2] - l[2]);
+                md = min(md, (int)(diff < (long long)INT_MAX ? diff : (long long)INT_MAX));
             }
         }
     }
-    // eight values per thread -> per wave (shuffles) -> per workgroup (LDS) -> eight atomics per workgroup
+    // eight values per thread -> per wave (shuffles) -> per workgroup (LDS) -> the workgroup's set
     int v[8] = { mn[0], mn[1], mn[2], mx[0], mx[1], mx[2], md, bad };
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -290,7 +286,7 @@ __global__ __launch_bounds__(256) void k_frame_quantize(int n, const float4 *__r
         const bool is_max = (k >= 3 && k < 6) || k == 7;
         int r = red[k][0];
         for (int w = 1; w < 4; w++) r = is_max ? max(r, red[k][w]) : min(r, red[k][w]);
-        if (is_max) atomicMax(&stats[k], r); else atomicMin(&stats[k], r);
+        stats[8 * blockIdx.x + k] = r;
     }
 }
 
@@ -330,14 +326,14 @@ extern "C" int mdx_frame_ring(mdx_system *s, int nslots)
         MDX_CHECK(s, hipHostMalloc((void **)&f.x, bytes, hipHostMallocDefault));
         MDX_CHECK(s, hipHostMalloc((void **)&f.v, bytes, hipHostMallocDefault));
         MDX_CHECK(s, hipHostMalloc((void **)&f.box, sizeof(double) * 9, hipHostMallocDefault));
-        MDX_CHECK(s, hipHostMalloc((void **)&f.stats, sizeof(int) * 8, hipHostMallocDefault));
+        MDX_CHECK(s, hipHostMalloc((void **)&f.stats, sizeof(int) * 8 * MDX_FRAME_WGS, hipHostMallocDefault));
         MDX_CHECK(s, hipEventCreateWithFlags(&f.ev, hipEventDisableTiming));
         MDX_CHECK(s, hipEventCreateWithFlags(&f.ev_staged, hipEventDisableTiming));
     }
     // one staging buffer per slot so that consecutive captures do not wait for each other
     MDX_CHECK(s, hipMalloc((void **)&r->d_stage, 2 * bytes * nslots));
     MDX_CHECK(s, hipMalloc((void **)&r->d_box, sizeof(double) * 9 * nslots));
-    MDX_CHECK(s, hipMalloc((void **)&r->d_stats, sizeof(int) * 8 * nslots));
+    MDX_CHECK(s, hipMalloc((void **)&r->d_stats, sizeof(int) * 8 * MDX_FRAME_WGS * nslots));
     return MDX_OK;
 }
 
@@ -351,11 +347,10 @@ static int capture_frame(mdx_system *s, int slot, int want_v, bool quantize, flo
     const size_t cnt = 3 * (size_t)n;
     float *dx = r->d_stage + 2 * cnt * slot, *dv = dx + cnt;
     double *dbox = r->d_box + 9 * slot;
-    int *dstats = r->d_stats + 8 * slot;
+    int *dstats = r->d_stats + 8 * MDX_FRAME_WGS * slot;
     if (want_v) hipLaunchKernelGGL(k_unpack3, dim3(nb), dim3(256), 0, s->stream, n, s->v, dv, nullptr, nullptr);
     if (quantize) {
-        hipLaunchKernelGGL(k_frame_stats_init, dim3(1), dim3(64), 0, s->stream, dstats);
-        hipExtLaunchKernelGGL(k_frame_quantize, dim3(nb), dim3(256), 0, s->stream, nullptr, f.ev_staged, 0, n, (const float4 *)s->x,
+        hipExtLaunchKernelGGL(k_frame_quantize, dim3(MDX_FRAME_WGS), dim3(256), 0, s->stream, nullptr, f.ev_staged, 0, n, (const float4 *)s->x,
                               precision, (int *)dx, dstats, (const double *)s->d->boxd, dbox);
     } else {
         hipExtLaunchKernelGGL(k_unpack3, dim3(nb), dim3(256), 0, s->stream, nullptr, f.ev_staged, 0, n, (const float4 *)s->x, dx,
@@ -367,7 +362,7 @@ static int capture_frame(mdx_system *s, int slot, int want_v, bool quantize, flo
     MDX_CHECK(s, hipMemcpyAsync(f.x, dx, sizeof(float) * cnt, hipMemcpyDeviceToHost, cs));
     if (want_v) MDX_CHECK(s, hipMemcpyAsync(f.v, dv, sizeof(float) * cnt, hipMemcpyDeviceToHost, cs));
     MDX_CHECK(s, hipMemcpyAsync(f.box, dbox, sizeof(double) * 9, hipMemcpyDeviceToHost, cs));
-    if (quantize) MDX_CHECK(s, hipMemcpyAsync(f.stats, dstats, sizeof(int) * 8, hipMemcpyDeviceToHost, cs));
+    if (quantize) MDX_CHECK(s, hipMemcpyAsync(f.stats, dstats, sizeof(int) * 8 * MDX_FRAME_WGS, hipMemcpyDeviceToHost, cs));
     MDX_CHECK(s, hipEventRecord(f.ev, cs));
     f.step = s->step; f.has_v = want_v ? 1 : 0; f.quantized = quantize ? 1 : 0;
     return MDX_OK;
@@ -412,6 +407,14 @@ extern "C" int mdx_frame_wait_xtc(mdx_system *s, int slot, const int **ix, const
     if (v) *v = f.has_v ? f.v : nullptr;
     if (box9) memcpy(box9, f.box, sizeof(double) * 9);
     if (step) *step = f.step;
-    if (stats8) memcpy(stats8, f.stats, sizeof(int) * 8);
+    if (stats8) {
+        // fold the workgroups' sets: minima, maxima, the smallest difference, the out-of-range flag
+        for (int k = 0; k < 8; k++) {
+            const bool is_max = (k >= 3 && k < 6) || k == 7;
+            int r = f.stats[k];
+            for (int w = 1; w < MDX_FRAME_WGS; w++) r = is_max ? std::max(r, f.stats[8 * w + k]) : std::min(r, f.stats[8 * w + k]);
+            stats8[k] = r;
+        }
+    }
     return MDX_OK;
 }
