@@ -156,7 +156,7 @@ extern "C" void mdx_destroy(mdx_system *s)
                      s->col_count, s->col_astart, s->col_scstart, s->col_atoms, s->atom_col, s->atom_slot, s->wrapped, s->cj, s->work, s->work_order, s->sc_nwork,
                      s->exclmask, s->shift_ijk, s->shiftvec, s->bond_ij, s->bond_p, s->angle_ijk, s->angle_p, s->dih_ijkl, s->dih_p,
                      s->pair_ij, s->pair_p, s->posres_idx, s->posres_ref, s->posres_k, s->settle_idx, s->cons_ij, s->cons_len,
-                     s->comp_start, s->comp_atom_start, s->comp_atoms, s->comp_local, s->free_atoms, s->d_tc, s->pull_idx[0], s->pull_idx[1], s->gtab, s->htab, s->dd_q0, s->dd_invm0, s->dd_lj0,
+                     s->comp_start, s->comp_atom_start, s->comp_atoms, s->comp_local, s->free_atoms, s->d_tc, s->ke_part, s->pull_idx[0], s->pull_idx[1], s->gtab, s->htab, s->dd_q0, s->dd_invm0, s->dd_lj0,
                      s->cj_in[0], s->cj_in[1], s->work_in[0], s->work_in[1], s->order_in[0], s->order_in[1], s->d };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (s->h) (void)hipHostFree(s->h);
@@ -506,6 +506,7 @@ extern "C" int mdx_set_tcoupl(mdx_system *s, int ng, const double *ref_t, const 
     if (ng == 0 && ndf) s->ndf_total = ndf[0];
     MDX_CHECK(s, hipMemcpy(s->d_tc, buf, sizeof(buf), hipMemcpyHostToDevice));
     s->first_step = true;
+    s->tc_fold_pending = false;        // (factors still owed from the old settings: the first step draws them afresh)
     return MDX_OK;
 }
 
@@ -637,6 +638,8 @@ static int sync_and_check(mdx_system *s)
 {
     // (a pruning launch is the one piece of work that no step joins into the main stream: it ends on the bonded stream)
     if (s->prune_pending) { MDX_CHECK(s, hipStreamSynchronize(s->st_bond)); s->prune_pending = false; }
+    // (thermostat factors still to be drawn from the last update's kinetic-energy sums: normally the next step's bonded stream does it)
+    if (s->tc_fold_pending) { s->tc_fold_pending = false; const int rc = mdx_launch_tcouple_fold(s, s->stream, s->tc_fold_step); if (rc) return rc; }
     MDX_CHECK(s, hipMemcpyAsync(s->h, s->d, sizeof(DevState), hipMemcpyDeviceToHost, s->stream));
     MDX_CHECK(s, hipStreamSynchronize(s->stream));
     if (s->h->overflow) {
@@ -911,7 +914,7 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
     const bool do_pc = s->pcoupl != 0 && (step % s->nstpcouple == 0);
     const bool need_vir = do_ener || do_pc;
     const bool tc_apply = s->ntc > 0 && (step % s->nsttcouple == 0);
-    bool pruned = false, do_prune = false;
+    bool pruned = false, do_prune = false, ke_in_update = false;
     if (phase != 2) {
         if (s->first_step && s->ntc > 0 && !(s->dd_on && !s->dd_own_tcouple)) {
             if ((rc = mdx_launch_clear(s, false, true, false))) return rc;
@@ -929,6 +932,9 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
         if (prepared) { if (!forked_early) if ((rc = mdx_fork(s))) return rc; }
         else if ((rc = mdx_launch_prepare(s, !forked_early))) return rc;
         prepared = false;
+        // Thermostat factors of the coupling period that the previous step ended: drawn on the bonded stream, which has just
+        // been released behind that step's update; the join orders it ahead of this step's update, the first to use them.
+        if (s->tc_fold_pending) { s->tc_fold_pending = false; if ((rc = mdx_launch_tcouple_fold(s, s->st_bond, s->tc_fold_step))) return rc; }
         // the nonbonded kernel is the critical path: enqueue it first, the side streams fill in
         if ((rc = mdx_launch_nonbonded(s, need_vir, MDX_F_NONBONDED | (s->have_pme ? MDX_F_EXCL : 0)))) return rc;
         if (phase == 0) {
@@ -975,10 +981,12 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
         // Steps that accumulate no virial take leap-frog and constraints in one launch, which (when another step of this
         // call follows on the same pair list and the cell stays as it is) also writes that step's sorted coordinates.
         const bool fused = phase == 0 && !need_vir && !s->dd_on && s->fused_update && mdx_fused_plan(s) == 1;
+        // a step that ends a coupling period of the thermostat: the fused update also sums the new kinetic energy
+        ke_in_update = fused && s->ntc > 0 && ((step + 1) % s->nsttcouple == 0);
         if (fused) {
             prepared = more && !search_next;
             if (prepared) if ((rc = mdx_wait_prune(s))) return rc;        // the launch rewrites the sorted coordinates
-            if ((rc = mdx_launch_update_fused(s, tc_apply, s->pcoupl == 2, prepared, fork_now && prepared))) return rc;
+            if ((rc = mdx_launch_update_fused(s, tc_apply, s->pcoupl == 2, prepared, fork_now && prepared, ke_in_update))) return rc;
             if (fork_now && prepared) forked_early = true;
         } else if ((rc = mdx_launch_update(s, tc_apply, s->pcoupl == 2, need_vir))) return rc;
         if (fork_now && !forked_early) {
@@ -994,7 +1002,13 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
         if ((rc = mdx_launch_finish_energy(s, do_ener ? next_energy_frame(s) : nullptr, do_pc && !s->dd_on))) return rc;
         if (do_ener) frame_steps(s).push_back(step);
     }
-    if (s->ntc > 0 && ((step + 1) % s->nsttcouple == 0) && !need_vir && !s->dd_on) {
+    if (ke_in_update) {
+        // The factors for the coming period come from the sums the update has left. Nothing uses them before the next
+        // update, so they are drawn beside the next step: on the bonded stream, at once when this step's update has
+        // released that stream already, otherwise when the next step releases it.
+        s->tc_fold_pending = true; s->tc_fold_step = step;
+        if (forked_early) { s->tc_fold_pending = false; if ((rc = mdx_launch_tcouple_fold(s, s->st_bond, step))) return rc; }
+    } else if (s->ntc > 0 && ((step + 1) % s->nsttcouple == 0) && !need_vir && !s->dd_on) {
         // the thermostat's own accumulator, which the kernel that draws the factor leaves zeroed: no clearing launch
         if ((rc = mdx_launch_ke(s, false, false, nullptr, true))) return rc;
         if ((rc = mdx_launch_tcouple(s, nullptr, true))) return rc;

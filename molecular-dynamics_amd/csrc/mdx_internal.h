@@ -224,6 +224,8 @@ struct mdx_system {
     int ntc = 0; double ref_t[MDX_MAX_TC] = {0}, tau_t[MDX_MAX_TC] = {0}, ndf[MDX_MAX_TC] = {0};
     int nsttcouple = 10; uint64_t seed = 1;
     double *d_tc = nullptr;       // device: ref_t, tau_t, ndf (3 x MDX_MAX_TC)
+    double *ke_part = nullptr; int ke_part_cap = 0, ke_parts = 0;    // per-workgroup kinetic-energy sums of the fused update (KE variant)
+    bool tc_fold_pending = false; long long tc_fold_step = 0;       // ... not yet folded into the thermostat's factors (mdx_flush_tcouple)
     double ndf_total = 0;
     int pcoupl = 0;               // 0 no, 1 C-rescale, 2 Parrinello-Rahman
     double tau_p = 1.0, ref_p = 1.0, compress = 4.5e-5; int nstpcouple = 10;
@@ -292,7 +294,8 @@ int mdx_launch_pull(mdx_system *s, bool log_now, bool energy);
 int mdx_launch_update(mdx_system *s, bool do_tc, bool do_pr, bool virial);
 int mdx_launch_constrain(mdx_system *s, float inv_dt, bool virial, int lincs_iter);
 int mdx_fused_plan(mdx_system *s);
-int mdx_launch_update_fused(mdx_system *s, bool do_tc, bool do_pr, bool write_sorted, bool fork_signal);
+int mdx_launch_update_fused(mdx_system *s, bool do_tc, bool do_pr, bool write_sorted, bool fork_signal, bool with_ke = false);
+int mdx_launch_tcouple_fold(mdx_system *s, hipStream_t st, long long step);
 void mdx_frames_free(mdx_system *s);
 int mdx_launch_ke(mdx_system *s, bool old_slot, bool tensor, hipStream_t st = nullptr, bool tc_slot = false);
 int mdx_launch_comm_phase(mdx_system *s, int phase);

@@ -306,6 +306,7 @@ struct FusedArgs {
     const int2 *comp_local;     // per constraint: positions of its two atoms in the component's atom list
     int write_sorted; const int *shift_s; float4 *xq_s;
     int settle_first;           // >= 0: atom `role` of water w is settle_first + 3 w + role (no index load)
+    double *ke_part;            // KE variant: MDX_MAX_TC partial sums per workgroup of the new half-step kinetic energy per T-group
 };
 __device__ __forceinline__ void d_sorted_write(const FusedArgs &A, const int g, const float4 p)
 {
@@ -319,15 +320,23 @@ __device__ __forceinline__ void d_sorted_write(const FusedArgs &A, const int g, 
     o.w = p.w;
     A.xq_s[g] = o;
 }
+// 1/2 m v^2 of one atom (v.w: inverse mass) added to its T-group's entry (compile-time indices: the array stays in registers)
+__device__ __forceinline__ void d_ke_add(float *keg, const int g, const float4 v)
+{
+    const float ke = v.w > 0.0f ? 0.5f * (v.x * v.x + v.y * v.y + v.z * v.z) / v.w : 0.0f;
+#pragma unroll
+    for (int k = 0; k < MDX_MAX_TC; k++) keg[k] += (g == k) ? ke : 0.0f;
+}
 // A constraint component in the fused update: its thread advances the component's atoms, keeps their new positions and
 // velocities in a private column of LDS (slot k of atom k of the component's atom list; `nthr` columns side by side, so
 // neighbouring threads use neighbouring banks), runs LINCS on those and stores every atom once. The separate LINCS
 // kernel updates positions and velocities in global memory constraint by constraint, and every such read-modify-write
 // waits a memory round trip for the one before it (an atom shared by two constraints): about 10 us per launch, which
 // in a fused kernel would sit behind the leap-frog of the same thread.
+// (keg, when given: the kinetic energy 1/2 m v^2 of the component's atoms after the update, added per T-group)
 template <int MAXK>
 __device__ __forceinline__ void d_fused_lincs(const FusedArgs &A, const int t, const int comp0, const int ncomp, float *sh,
-                                              const int tid, const int nthr)
+                                              const int tid, const int nthr, float *keg = nullptr)
 {
     constexpr int NA = MAXK + 1;
     const ConstrainArgs &C = A.C;
@@ -409,9 +418,14 @@ __device__ __forceinline__ void d_fused_lincs(const FusedArgs &A, const int t, c
             C.xp[ai[k]] = xo;
             C.v[ai[k]] = make_float4(S(k, 3), S(k, 4), S(k, 5), S(k, 6));
             if (A.write_sorted) d_sorted_write(A, gi[k], xo);
+            if (keg) d_ke_add(keg, A.L.tcgrp[ai[k]], make_float4(S(k, 3), S(k, 4), S(k, 5), S(k, 6)));
         }
 }
 #define MDX_FUSED_LARGE_THREADS 32      // threads of a workgroup that take a component of more than 4 constraints (LDS columns of 17 atoms)
+// KE: the launch also leaves the half-step kinetic energy of the new velocities per T-group, as one set of partial sums per
+// workgroup (plain stores; the kernel that draws the thermostat's factors folds them): on the steps that end a coupling
+// period the kinetic energy then needs no pass of its own over the velocities behind the update.
+template <bool KE>
 __global__ __launch_bounds__(128) void k_update_fused(FusedArgs A)
 {
     MDX_STAMP(A.C.dw, 11);
@@ -419,6 +433,9 @@ __global__ __launch_bounds__(128) void k_update_fused(FusedArgs A)
     static_assert((MDX_LINCS_MAXK + 1) * 7 * MDX_FUSED_LARGE_THREADS <= 5 * 7 * 128, "LDS columns of the large components");
     const ConstrainArgs &C = A.C;
     const int b = blockIdx.x;
+    float keg[MDX_MAX_TC];
+#pragma unroll
+    for (int k = 0; k < MDX_MAX_TC; k++) keg[k] = 0.0f;
     if (A.write_sorted && b == 0 && threadIdx.x < 8) C.dw->nb_head[threadIdx.x * 32] = 0;
     if (b < A.nbw3) {
         // One lane per atom, three consecutive lanes per water (21 waters per wave, the last lane idles): the leap-frog of
@@ -445,29 +462,42 @@ __global__ __launch_bounds__(128) void k_update_fused(FusedArgs A)
             xn[r] = make_float3(__shfl(xpo.x, src, 64), __shfl(xpo.y, src, 64), __shfl(xpo.z, src, 64));
             if (r < 2) im[r] = __shfl(vi.w, src, 64);
         }
-        if (!valid) return;
-        float3 dO, dH1, dH2, r0[3];
-        float lam[3];
-        settle_solve(xo[0], xo[1], xo[2], xn[0], xn[1], xn[2], im[0], im[1], C.doh, C.dhh, dO, dH1, dH2, lam, r0);
-        const float3 dd = role == 0 ? dO : (role == 1 ? dH1 : dH2);
-        xpo = make_float4(xpo.x + dd.x, xpo.y + dd.y, xpo.z + dd.z, xpo.w);
-        vi = make_float4(vi.x + dd.x * C.inv_dt, vi.y + dd.y * C.inv_dt, vi.z + dd.z * C.inv_dt, vi.w);
-        C.xp[i] = xpo; C.v[i] = vi;
-        if (A.write_sorted) d_sorted_write(A, g, xpo);
+        if (valid) {
+            float3 dO, dH1, dH2, r0[3];
+            float lam[3];
+            settle_solve(xo[0], xo[1], xo[2], xn[0], xn[1], xn[2], im[0], im[1], C.doh, C.dhh, dO, dH1, dH2, lam, r0);
+            const float3 dd = role == 0 ? dO : (role == 1 ? dH1 : dH2);
+            xpo = make_float4(xpo.x + dd.x, xpo.y + dd.y, xpo.z + dd.z, xpo.w);
+            vi = make_float4(vi.x + dd.x * C.inv_dt, vi.y + dd.y * C.inv_dt, vi.z + dd.z * C.inv_dt, vi.w);
+            C.xp[i] = xpo; C.v[i] = vi;
+            if (A.write_sorted) d_sorted_write(A, g, xpo);
+            if (KE) d_ke_add(keg, A.L.tcgrp[i], vi);
+        }
     } else if (b < A.nbw3 + C.nb4) {
-        d_fused_lincs<4>(A, (b - A.nbw3) * 128 + threadIdx.x, 0, C.ncomp_small, sh, threadIdx.x, 128);
+        d_fused_lincs<4>(A, (b - A.nbw3) * 128 + threadIdx.x, 0, C.ncomp_small, sh, threadIdx.x, 128, KE ? keg : nullptr);
     } else if (b < A.nbw3 + C.nb4 + A.nbfree) {
         const int t = (b - A.nbw3 - C.nb4) * 128 + threadIdx.x;
-        if (t >= A.nfree) return;
-        const int i = A.free_atoms[t];
-        float4 vi = C.v[i], xo; int g;
-        d_leap(A.L, i, C.x[i], vi, xo, g);
-        C.v[i] = vi; C.xp[i] = xo;
-        if (A.write_sorted) d_sorted_write(A, g, xo);
+        if (t < A.nfree) {
+            const int i = A.free_atoms[t];
+            float4 vi = C.v[i], xo; int g;
+            d_leap(A.L, i, C.x[i], vi, xo, g);
+            C.v[i] = vi; C.xp[i] = xo;
+            if (A.write_sorted) d_sorted_write(A, g, xo);
+            if (KE) d_ke_add(keg, A.L.tcgrp[i], vi);
+        }
     } else {
         if (threadIdx.x < MDX_FUSED_LARGE_THREADS)
             d_fused_lincs<MDX_LINCS_MAXK>(A, C.ncomp_small + (b - A.nbw3 - C.nb4 - A.nbfree) * MDX_FUSED_LARGE_THREADS + threadIdx.x, C.ncomp_small,
-                                          C.ncomp - C.ncomp_small, sh, threadIdx.x, MDX_FUSED_LARGE_THREADS);
+                                          C.ncomp - C.ncomp_small, sh, threadIdx.x, MDX_FUSED_LARGE_THREADS, KE ? keg : nullptr);
+    }
+    if (KE) {
+        // (every thread of the workgroup arrives here: no path above returns early)
+        __shared__ double red[16 * MDX_MAX_TC];
+        double all[MDX_MAX_TC];
+#pragma unroll
+        for (int k = 0; k < MDX_MAX_TC; k++) all[k] = (double)keg[k];
+        const double r = block_sum_n<MDX_MAX_TC>(all, red);
+        if (threadIdx.x < MDX_MAX_TC) A.ke_part[(size_t)b * MDX_MAX_TC + threadIdx.x] = r;
     }
 }
 
@@ -514,30 +544,53 @@ __global__ __launch_bounds__(256) void k_ke(int n, const float4 *__restrict__ v,
 // V-rescale (Bussi, Donadio, Parrinello 2007): one thread per group draws the group's new kinetic energy
 // from the half-step kinetic energy just computed and stores lambda for the coming step.
 // tc_slot: the kinetic energy comes from the accumulator of the side-stream thermostat, which is left zeroed for the next use.
+__device__ __forceinline__ void d_tcouple_draw(DevState *dw, const int g, const double ek, const double *ref_t, const double *tau_t,
+                                               const double *ndf, double dt_tc, unsigned long long seed, long long step)
+{
+    double lam = 1.0;
+    if (ek > 0.0 && tau_t[g] > 0.0 && ndf[g] > 0.0) {
+        const double ekref = 0.5 * ndf[g] * MDX_BOLTZ * ref_t[g];
+        const double c = exp(-dt_tc / tau_t[g]);
+        RngStream rng(seed, 0x7c0000ull + g, (uint64_t)step);
+        const double r1 = rng.gauss();
+        const double rs = rng.chi2(ndf[g] - 1.0);
+        const double eknew = ek + (1.0 - c) * (ekref * (rs + r1 * r1) / ndf[g] - ek) +
+                             2.0 * r1 * sqrt(c * (1.0 - c) * ek * ekref / ndf[g]);
+        lam = sqrt(fmax(eknew, 0.0) / ek);
+        dw->therm_integral[g] -= (eknew - ek);
+    }
+    dw->lambda[g] = lam;
+}
 __global__ void k_tcouple(DevState *dw, int ntc, const double *ref_t, const double *tau_t, const double *ndf,
                           double dt_tc, unsigned long long seed, long long step, int tc_slot)
 {
     MDX_STAMP(dw, 15);
     // one thread per group (the groups' draws are independent streams)
     if (blockIdx.x != 0 || (int)threadIdx.x >= ntc) return;
-    {
-        const int g = threadIdx.x;
-        const double ek = tc_slot ? dw->ekinh_tc[g] : dw->ekinh[g];
-        if (tc_slot) dw->ekinh_tc[g] = 0.0;
-        double lam = 1.0;
-        if (ek > 0.0 && tau_t[g] > 0.0 && ndf[g] > 0.0) {
-            const double ekref = 0.5 * ndf[g] * MDX_BOLTZ * ref_t[g];
-            const double c = exp(-dt_tc / tau_t[g]);
-            RngStream rng(seed, 0x7c0000ull + g, (uint64_t)step);
-            const double r1 = rng.gauss();
-            const double rs = rng.chi2(ndf[g] - 1.0);
-            const double eknew = ek + (1.0 - c) * (ekref * (rs + r1 * r1) / ndf[g] - ek) +
-                                 2.0 * r1 * sqrt(c * (1.0 - c) * ek * ekref / ndf[g]);
-            lam = sqrt(fmax(eknew, 0.0) / ek);
-            dw->therm_integral[g] -= (eknew - ek);
-        }
-        dw->lambda[g] = lam;
-    }
+    const int g = threadIdx.x;
+    const double ek = tc_slot ? dw->ekinh_tc[g] : dw->ekinh[g];
+    if (tc_slot) dw->ekinh_tc[g] = 0.0;
+    d_tcouple_draw(dw, g, ek, ref_t, tau_t, ndf, dt_tc, seed, step);
+}
+// The same from the partial sums a fused update (KE variant) left per workgroup: one workgroup folds them, then one
+// thread per group draws.
+__global__ __launch_bounds__(256) void k_tcouple_fold(DevState *dw, int ntc, const double *ref_t, const double *tau_t, const double *ndf,
+                                                      double dt_tc, unsigned long long seed, long long step,
+                                                      const double *__restrict__ ke_part, int nparts)
+{
+    MDX_STAMP(dw, 15);
+    __shared__ double red[16 * MDX_MAX_TC];
+    __shared__ double ek_s[MDX_MAX_TC];
+    double acc[MDX_MAX_TC];
+#pragma unroll
+    for (int k = 0; k < MDX_MAX_TC; k++) acc[k] = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += blockDim.x)
+#pragma unroll
+        for (int k = 0; k < MDX_MAX_TC; k++) acc[k] += ke_part[(size_t)p * MDX_MAX_TC + k];
+    const double r = block_sum_n<MDX_MAX_TC>(acc, red);
+    if (threadIdx.x < MDX_MAX_TC) ek_s[threadIdx.x] = r;
+    __syncthreads();
+    if ((int)threadIdx.x < ntc) d_tcouple_draw(dw, threadIdx.x, ek_s[threadIdx.x], ref_t, tau_t, ndf, dt_tc, seed, step);
 }
 
 // Barostat parameters of one coupling step (kind 0: none).
@@ -820,7 +873,7 @@ int mdx_fused_plan(mdx_system *s)
 // The fused update of a step without virial (mdx_fused_plan must have returned 1). write_sorted: also leave the sorted
 // coordinates, the cleared sorted force buffer and the reset unit queues for the next step; fork_signal: the kernel's
 // completion releases the PME and bonded streams (their next kernels read the new positions only).
-int mdx_launch_update_fused(mdx_system *s, bool do_tc, bool do_pr, bool write_sorted, bool fork_signal)
+int mdx_launch_update_fused(mdx_system *s, bool do_tc, bool do_pr, bool write_sorted, bool fork_signal, bool with_ke)
 {
     FusedArgs A;
     constrain_args(s, A.C, 1.0f / s->dt, s->lincs_iter);
@@ -832,14 +885,25 @@ int mdx_launch_update_fused(mdx_system *s, bool do_tc, bool do_pr, bool write_so
     const int nb16 = (s->ncomp - s->ncomp_small + MDX_FUSED_LARGE_THREADS - 1) / MDX_FUSED_LARGE_THREADS;
     A.nbw3 = (s->nsettle + 41) / 42;
     const int nblocks = A.nbw3 + A.C.nb4 + A.nbfree + nb16;
+    A.ke_part = nullptr;
+    if (with_ke) {
+        if (s->ke_part_cap < nblocks) {
+            if (s->ke_part) (void)hipFree(s->ke_part);
+            s->ke_part = nullptr; s->ke_part_cap = 0;
+            MDX_CHECK(s, hipMalloc((void **)&s->ke_part, sizeof(double) * MDX_MAX_TC * (size_t)nblocks));
+            s->ke_part_cap = nblocks;
+        }
+        A.ke_part = s->ke_part; s->ke_parts = nblocks;
+    }
+    void (*kern)(FusedArgs) = with_ke ? k_update_fused<true> : k_update_fused<false>;
     if (nblocks > 0) {
         if (fork_signal) {
-            hipExtLaunchKernelGGL(k_update_fused, dim3(nblocks), dim3(128), 0, s->stream, nullptr, s->ev_fork, 0, A);
+            hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(128), 0, s->stream, nullptr, s->ev_fork, 0, A);
             MDX_CHECK(s, hipGetLastError());
             MDX_CHECK(s, hipStreamWaitEvent(s->st_pme, s->ev_fork, 0));
             MDX_CHECK(s, hipStreamWaitEvent(s->st_bond, s->ev_fork, 0));
         } else {
-            hipLaunchKernelGGL(k_update_fused, dim3(nblocks), dim3(128), 0, s->stream, A);
+            hipLaunchKernelGGL(kern, dim3(nblocks), dim3(128), 0, s->stream, A);
             MDX_CHECK(s, hipGetLastError());
         }
     }
@@ -917,6 +981,17 @@ int mdx_launch_tcouple(mdx_system *s, hipStream_t st, bool tc_slot)
     if (s->ntc <= 0) return MDX_OK;
     hipLaunchKernelGGL(k_tcouple, dim3(1), dim3(64), 0, st ? st : s->stream, s->d, s->ntc, s->d_tc, s->d_tc + MDX_MAX_TC,
                        s->d_tc + 2 * MDX_MAX_TC, (double)s->nsttcouple * s->dt, (unsigned long long)s->seed, s->step, tc_slot ? 1 : 0);
+    MDX_CHECK(s, hipGetLastError());
+    return MDX_OK;
+}
+
+// The thermostat's factors from the partial sums of the last fused update with kinetic energy, on stream `st`.
+// `step`: the step counter the draw is keyed by (that of the step which ended the coupling period).
+int mdx_launch_tcouple_fold(mdx_system *s, hipStream_t st, long long step)
+{
+    if (s->ntc <= 0 || !s->ke_part) return MDX_OK;
+    hipLaunchKernelGGL(k_tcouple_fold, dim3(1), dim3(256), 0, st, s->d, s->ntc, s->d_tc, s->d_tc + MDX_MAX_TC, s->d_tc + 2 * MDX_MAX_TC,
+                       (double)s->nsttcouple * s->dt, (unsigned long long)s->seed, step, (const double *)s->ke_part, s->ke_parts);
     MDX_CHECK(s, hipGetLastError());
     return MDX_OK;
 }
