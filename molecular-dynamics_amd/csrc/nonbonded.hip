@@ -29,7 +29,6 @@ struct NbArgs {
     float *f_s;
     DevState *dw;
     float rc2, beta, c_rf_shift; // c_rf_shift = erfc(beta rc)/rc
-    float inv_rc6;               // 1/rc^6
     int central;                 // index of the zero lattice shift
     int do_pairs, do_excl;       // evaluate listed pairs / the Ewald correction of excluded pairs
     const float4 *htab;          // MDX_GTAB_N entries (g, step of g, h, step of h), h(w) = erf(z)/z
@@ -580,7 +579,6 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
     A.shiftvec = s->shiftvec; A.f_s = s->f_s;
     A.rc2 = s->rc * s->rc; A.beta = s->beta;
     A.c_rf_shift = (float)(erfc((double)s->beta * s->rc) / s->rc);
-    A.inv_rc6 = 1.0f / (A.rc2 * A.rc2 * A.rc2);
     // kernel timing samples launches of the step loop: the start and stop events ride on the kernel's own dispatch
     // packet, so they read the kernel's begin and end time stamps (no marker packets, no launch gap inside)
     hipEvent_t ev_a = nullptr, ev_b = nullptr;

@@ -432,7 +432,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
                             const int cjg = scj * 8 + cjl;
                             // atom level: lane = (i-atom ti, j-atom tj); the lane's eight i-atoms are in registers
                             const float4 xj = xj_sh[wv][cjl * 8 + tj];
-                            const int origj = origj_sh[wv][cjl * 8 + tj];
                             const float xjs = xj.x + S.x, yjs = xj.y + S.y, zjs = xj.z + S.z;
                             const unsigned sure = (unsigned)((cs >> (8 * cjl)) & 0xFFull);
                             unsigned newim = sure, exb = 0xFF;

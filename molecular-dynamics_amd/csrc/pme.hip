@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_pme_spread_slab(SpreadSlabArgs A, const
     const int tlo = A.tlo0 + blockIdx.y * A.SP;
     const DevBox &bx = d->box;
     const float wx = bx.h[0] / A.ncx, wy = bx.h[4] / A.ncy;
-    const float x_lo = cx0 * wx - A.delta, x_hi = (cx0 + ncolx) * wx + A.delta;
+    const float x_lo = cx0 * wx - A.delta;
     const float y_lo = cy0 * wy - A.delta, y_hi = (cy0 + ncoly) * wy + A.delta;
     const float kz = A.K2 * bx.inv[8];
     if (threadIdx.x == 0) s_n = 0;
