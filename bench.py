@@ -96,7 +96,9 @@ def find_gromacs():
 
 def run_dd(args, rank, world, local):
     """Tiled water box (S1 x 2x2x2, ~1.1e6 atoms) stepped by all ranks together: halo exchange of positions every
-    step, one all-reduce of the charge grid, partition renewed every pair-list lifetime. NVT, dt 2 fs, rc 1.0 nm."""
+    step, the mesh transform shared by planes of the half-complex grid (or one all-reduce of the charge grid where the
+    grid's planes do not fit the plane kernel: `config.mesh`), partition renewed every pair-list lifetime. NVT, dt 2 fs,
+    rc 1.0 nm."""
     import torch
     import torch.distributed as dist
     from mdx import synth, engine as eng, domdec
@@ -133,7 +135,7 @@ def run_dd(args, rank, world, local):
             "config": {"workload": "tiled TIP3P box S4 (%d atoms), spatial domain decomposition %s, NVT, dt 2 fs, rc 1.0 nm, PME 0.16 nm"
                                    % (big.natoms, "x".join(str(d) for d in dd.dims)),
                        "natoms": big.natoms, "home_molecules_rank0": dd.n_home, "halo_molecules_rank0": dd.n_halo,
-                       "rlist_nm": round(dd.rlist, 4), "nstlist": args.nstlist, "pme_grid": list(dd.engine.grid),
+                       "rlist_nm": round(dd.rlist, 4), "nstlist": args.nstlist, "pme_grid": list(dd.engine.grid), "mesh": dd.mesh,
                        "parallelism": "dd%d" % world}}), file=JSON_OUT, flush=True)
     dd.close()
     if world > 1:

@@ -277,6 +277,19 @@ int mdx_dd_state_pointers(mdx_system *sys, void **x4_dev, void **v4_dev);
  * between mdx_dd_step_begin and mdx_dd_step_end needs no mdx_dd_wait_spread and no host synchronisation; exchanges
  * and scalar sums go on the main stream the same way. No counterpart in the reference (single-rank mdrun). */
 int mdx_dd_streams(mdx_system *sys, void **main_stream, void **pme_stream);
+/* The mesh transform shared among the domains instead of solved by every one of them. No counterpart in the reference
+ * (single-rank mdrun); what a multi-rank gmx mdrun does with its PME decomposition. After mdx_dd_mesh_slabs(sys, world, rank)
+ * a step runs as: mdx_dd_step_begin (now through the x forward pass of this domain's own charge grid) -> the caller
+ * reduce-scatters the half-complex grid of mdx_dd_cgrid (`world` equal chunks of `planes_per_domain` k_x planes of
+ * `plane_elems` float2 each, chunk r summed onto domain r) -> mdx_dd_step_mid (y and z transforms, influence function and
+ * back on this domain's planes) -> the caller all-gathers the chunks -> mdx_dd_step_end (x inverse pass, gather, update).
+ * mdx_dd_wait_spread blocks until the stage begun last has finished; callers that order their collectives on the PME stream
+ * (mdx_dd_streams) need no wait. Every domain accumulates the reciprocal-space energy and virial of its own planes
+ * (mesh_energy = 1 on all of them): they add up like the other terms. MDX_ERR_UNSUPPORTED for a PME grid whose planes
+ * the fused plane kernel cannot take (the caller keeps mdx_dd_grid's scheme); world = 0 returns to that scheme. */
+int mdx_dd_mesh_slabs(mdx_system *sys, int world, int rank);
+int mdx_dd_cgrid(mdx_system *sys, void **cgrid_dev, int *planes_per_domain, long long *plane_elems);
+int mdx_dd_step_mid(mdx_system *sys);
 /* Quantities the domains have to agree on. Energy steps: every domain's energy terms, virial and pressure are
  * partial sums over the atoms it owns (a pair with a halo atom counts half on each side, the Ewald self term covers
  * the home atoms) and add up over the domains; the reciprocal-space energy and virial are the same on every domain,

@@ -14,10 +14,13 @@
 //   mdx_dd_step_begin / mdx_dd_wait_spread / mdx_dd_step_end
 //                    a step in two halves; between them the caller sums the charge grids of all domains
 //                    (mdx_dd_grid gives the device pointer) so that every domain solves the full mesh problem
+//   mdx_dd_mesh_slabs / mdx_dd_cgrid / mdx_dd_step_mid
+//                    the mesh problem shared instead: every domain transforms its own planes of the half-complex grid
 #include "mdx_internal.h"
 
 int mdx_step_begin_internal(mdx_system *s);
 int mdx_step_end_internal(mdx_system *s);
+int mdx_step_mid_internal(mdx_system *s);
 
 __global__ void k_dd_load(int ncap, int n_home, int n_total, const float4 *__restrict__ xin, const float4 *__restrict__ vin,
                           const float *__restrict__ q0, const float *__restrict__ invm0, const float2 *__restrict__ lj0,
@@ -139,6 +142,54 @@ extern "C" int mdx_dd_step_end(mdx_system *s)
     (void)hipSetDevice(s->device);
     if (!s->dd_on) { s->err = "mdx_dd_step_end: no partition loaded"; return MDX_ERR_ARG; }
     return mdx_step_end_internal(s);
+}
+
+// The mesh transform shared among `world` domains. The x passes of the 3D transform act on lines of one (y, z) each, and a
+// sum over domains commutes with them, so a domain can transform its own partial charge grid along x first; what the domains
+// then have to add up is the half-complex grid, stored as k_x planes of K2 x K1 values (y fastest), and each plane is a
+// self-contained problem for the y and z transforms and the influence function. With this call
+//   mdx_dd_step_begin   runs on through the x forward pass;
+//   the caller          reduce-scatters the grid of mdx_dd_cgrid: `world` equal chunks of `planes_per_domain` planes, chunk r
+//                       summed onto domain r (planes past K0 / 2 stay zero);
+//   mdx_dd_step_mid     transforms the planes of this domain's chunk (y, z, influence function, z and y back);
+//   the caller          all-gathers the chunks;
+//   mdx_dd_step_end     starts at the x inverse pass.
+// mdx_dd_wait_spread blocks until the stage begun last has finished. The reciprocal-space energy and virial of a domain
+// are those of its planes and add up over the domains (mesh_energy of mdx_dd_set_roles on for every domain).
+// Returns MDX_ERR_UNSUPPORTED for a grid whose planes the fused kernel cannot take (a dimension that does not split into
+// two factors <= 10, or a plane beyond the LDS budget): the caller then keeps the sum of the real-space grids.
+// world = 0 returns to that scheme.
+extern "C" int mdx_dd_mesh_slabs(mdx_system *s, int world, int rank)
+{
+    (void)hipSetDevice(s->device);
+    if (!s->have_pme) { s->err = "mdx_dd_mesh_slabs: PME is not set up"; return MDX_ERR_ARG; }
+    if (world < 0 || (world > 0 && (rank < 0 || rank >= world))) { s->err = "mdx_dd_mesh_slabs: need 0 <= rank < world"; return MDX_ERR_ARG; }
+    if (world > 0 && !(s->own_fft && s->fft_yz)) { s->err = "mdx_dd_mesh_slabs: this grid has no plane-wise transform"; return MDX_ERR_UNSUPPORTED; }
+    MDX_CHECK(s, hipDeviceSynchronize());
+    const int K0c = s->K[0] / 2 + 1;
+    s->dd_mesh_world = world;
+    s->dd_plane_chunk = world > 0 ? (K0c + world - 1) / world : 0;
+    s->dd_plane_first = world > 0 ? rank * s->dd_plane_chunk : 0;
+    s->dd_plane_count = world > 0 ? std::max(0, std::min(K0c, s->dd_plane_first + s->dd_plane_chunk) - s->dd_plane_first) : 0;
+    return mdx_pme_init(s);         // (the half-complex grid is sized by the chunks)
+}
+
+// Device pointer of the half-complex grid (float2, plane-major: plane k_x at k_x * plane_elems), the number of planes in
+// a domain's chunk and the values per plane (K1 * K2).
+extern "C" int mdx_dd_cgrid(mdx_system *s, void **cgrid_dev, int *planes_per_domain, long long *plane_elems)
+{
+    if (!s->have_pme || s->dd_mesh_world <= 0) { s->err = "mdx_dd_cgrid: call mdx_dd_mesh_slabs first"; return MDX_ERR_ARG; }
+    if (cgrid_dev) *cgrid_dev = s->cgrid;
+    if (planes_per_domain) *planes_per_domain = s->dd_plane_chunk;
+    if (plane_elems) *plane_elems = (long long)s->K[1] * s->K[2];
+    return MDX_OK;
+}
+
+extern "C" int mdx_dd_step_mid(mdx_system *s)
+{
+    (void)hipSetDevice(s->device);
+    if (!s->dd_on) { s->err = "mdx_dd_step_mid: no partition loaded"; return MDX_ERR_ARG; }
+    return mdx_step_mid_internal(s);
 }
 
 // Which parts of a step this domain's handle does on its own (default: all of them, as a single domain needs):

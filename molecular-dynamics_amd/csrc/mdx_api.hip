@@ -109,6 +109,7 @@ extern "C" mdx_system *mdx_create(int device, int natoms)
     const int n = natoms;
     // MDX_NB_DYN=0 in the environment selects the static deal of the nonbonded kernel (processes sharing one GPU)
     if (const char *e = getenv("MDX_NB_DYN")) s->nb_dyn = atoi(e);
+    if (const char *e = getenv("MDX_YZ_LDS_KB")) s->yz_lds_limit = std::max(0, std::min(158, atoi(e))) * 1024;
     s->ncol_cap = n / 128 + 256;
     s->npad = ((n + 63) / 64 + s->ncol_cap) * 64;
     s->cj_cap = (s->npad / 64) * MDX_CJ_PER_SC;
@@ -905,6 +906,8 @@ extern "C" int mdx_get_kernel_timing(mdx_system *s, double *ms, long long *launc
 // spreading and the short-range kernels and records ev_spread behind the spreading; the caller then sums the
 // charge grids of all domains; phase 2 enqueues the rest of the PME chain, the join, the update and the
 // coupling kernels. Phase 0 is the whole step. `more` tells that another step follows in the same call.
+// Domains that share the mesh transform (mdx_dd_mesh_slabs) cut the PME chain twice: phase 1 runs on through the x forward
+// pass, phase 3 transforms this domain's planes (ev_spread recorded behind it as well), phase 2 starts at the x inverse pass.
 static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, bool &prepared)
 {
     int rc;
@@ -915,6 +918,13 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
     const bool need_vir = do_ener || do_pc;
     const bool tc_apply = s->ntc > 0 && (step % s->nsttcouple == 0);
     bool pruned = false, do_prune = false, ke_in_update = false;
+    const bool slabs = s->dd_on && s->dd_mesh_world > 0 && s->have_pme;
+    if (phase == 3) {
+        if (!slabs) return MDX_OK;
+        if ((rc = mdx_launch_pme(s, need_vir && s->dd_mesh_energy, true, 2))) return rc;
+        MDX_CHECK(s, hipEventRecord(s->ev_spread, s->st_pme));
+        return MDX_OK;
+    }
     if (phase != 2) {
         if (s->first_step && s->ntc > 0 && !(s->dd_on && !s->dd_own_tcouple)) {
             if ((rc = mdx_launch_clear(s, false, true, false))) return rc;
@@ -940,7 +950,8 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
         if (phase == 0) {
             if ((rc = mdx_launch_pme(s, need_vir, false))) return rc;
         } else if (s->have_pme) {
-            if ((rc = mdx_launch_pme_spread(s, s->st_pme))) return rc;
+            if (slabs) { if ((rc = mdx_launch_pme(s, false, false, 1))) return rc; }
+            else if ((rc = mdx_launch_pme_spread(s, s->st_pme))) return rc;
             MDX_CHECK(s, hipEventRecord(s->ev_spread, s->st_pme));
         }
         if ((rc = mdx_launch_bonded(s, need_vir, MDX_F_BONDED | MDX_F_POSRES))) return rc;
@@ -956,7 +967,7 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
                    s->steps_since_search + 1 < s->nstlist;
         if (phase == 1) return MDX_OK;
     }
-    if (phase == 2) if ((rc = mdx_launch_pme(s, need_vir && s->dd_mesh_energy, true))) return rc;
+    if (phase == 2) if ((rc = slabs ? mdx_launch_pme(s, false, true, 3) : mdx_launch_pme(s, need_vir && s->dd_mesh_energy, true))) return rc;
     if ((rc = mdx_join(s))) return rc;
     if (do_prune) {
         // Beside this step's nonbonded kernel (which still reads the list of the last prune, or on a search step the outer
@@ -1049,6 +1060,7 @@ extern "C" int mdx_step(mdx_system *s, long long nsteps)
 // Domain decomposition: the two halves of a step around the summation of the charge grids (csrc/domdec.hip).
 int mdx_step_begin_internal(mdx_system *s) { bool fe = false, pr = false; return step_phase(s, 1, false, fe, pr); }
 int mdx_step_end_internal(mdx_system *s) { bool fe = false, pr = false; return step_phase(s, 2, false, fe, pr); }
+int mdx_step_mid_internal(mdx_system *s) { bool fe = false, pr = false; return step_phase(s, 3, false, fe, pr); }
 
 extern "C" long long mdx_pop_energy_frames(mdx_system *s, double *out, long long max_frames)
 {

@@ -196,7 +196,8 @@ struct mdx_system {
     float *bmod[3] = {nullptr, nullptr, nullptr};
     hipfftHandle plan_r2c = 0, plan_c2r = 0;
     float2 *fftW[3] = {nullptr, nullptr, nullptr};   // twiddle tables exp(-2 pi i j / K) of the own transform
-    bool fft_yz = false;          // ... and a k_x plane fits into LDS with factors <= 10: y and z passes fused into one launch
+    bool fft_yz = false;          // ... and a k_x plane fits into LDS with factors <= 16: y and z passes fused into one launch
+    bool fft_yz_big = false;      // ... in the form for planes beyond 96 KB or factors beyond 10
     bool own_fft = false;         // every grid dimension splits into two factors <= 32: the own transform is used
     bool have_pme = false;
     // bonded
@@ -263,6 +264,10 @@ struct mdx_system {
     bool dd_on = false;
     bool dd_mesh_energy = true;        // this domain accumulates the reciprocal-space energy and virial
     bool dd_own_tcouple = true;        // the step computes the thermostat factor itself (false: mdx_dd_tcouple after the caller's sum)
+    // mesh transform shared among the domains (mdx_dd_mesh_slabs): of the K0 / 2 + 1 planes of the half-complex grid this
+    // domain transforms [dd_plane_first, + dd_plane_count); the grid holds dd_mesh_world equal chunks of dd_plane_chunk planes
+    int yz_lds_limit = 96 * 1024;      // largest plane (with its twiddle tables) the fused y/z kernel takes; MDX_YZ_LDS_KB overrides (a CU has 160 KB)
+    int dd_mesh_world = 0, dd_plane_chunk = 0, dd_plane_first = 0, dd_plane_count = 0;
     float *dd_q0 = nullptr, *dd_invm0 = nullptr; float2 *dd_lj0 = nullptr;   // per-slot pattern as set up
     double search_density = 0.0;  // atoms per nm^3 for the sizing of the search grid (0: atoms / box volume)
     void *frame_ring = nullptr;   // pinned trajectory-frame slots (runctl.hip)
@@ -287,7 +292,9 @@ int mdx_fork(mdx_system *s);
 int mdx_join(mdx_system *s);
 int mdx_launch_prepare(mdx_system *s, bool fork = false);
 int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms);
-int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done = false);
+// stage 0: the whole chain; 1: spreading (unless done) and x forward; 2: y/z transforms and influence function on this
+// domain's planes; 3: x inverse and gather
+int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done = false, int stage = 0);
 int mdx_launch_pme_spread(mdx_system *s, hipStream_t st);
 int mdx_launch_bonded(mdx_system *s, bool energy, unsigned flags);
 int mdx_launch_pull(mdx_system *s, bool log_now, bool energy);

@@ -440,6 +440,11 @@ __device__ __forceinline__ void dft_pass2_r(float2 *a, const float2 *b, const fl
     case 2: F<2>(__VA_ARGS__); break; case 3: F<3>(__VA_ARGS__); break; case 4: F<4>(__VA_ARGS__); break; \
     case 5: F<5>(__VA_ARGS__); break; case 6: F<6>(__VA_ARGS__); break; case 7: F<7>(__VA_ARGS__); break; \
     case 8: F<8>(__VA_ARGS__); break; case 9: F<9>(__VA_ARGS__); break; case 10: F<10>(__VA_ARGS__); break;
+// radices 11 .. 16 for the plane kernel of large grids (160 = 10 x 16, 112 = 8 x 14, ...): only where BIG is set
+#define MDX_DFT_MAXR_BIG 16
+#define MDX_DFT_CASES_BIG(BIG, F, ...) \
+    case 11: if (BIG) F<11>(__VA_ARGS__); break; case 12: if (BIG) F<12>(__VA_ARGS__); break; case 13: if (BIG) F<13>(__VA_ARGS__); break; \
+    case 14: if (BIG) F<14>(__VA_ARGS__); break; case 15: if (BIG) F<15>(__VA_ARGS__); break; case 16: if (BIG) F<16>(__VA_ARGS__); break;
 __device__ __forceinline__ void dft_lines_fast(float2 *a, float2 *b, const float2 *W, int nl, int N, int N1, int N2, bool inverse)
 {
     if (N1 < 2 || N1 > MDX_DFT_MAXR || N2 < 2 || N2 > MDX_DFT_MAXR) { dft_lines(a, b, W, nl, N, N1, N2, inverse); return; }
@@ -587,6 +592,7 @@ struct FftYzArgs {
     float2 *cgrid;                      // (K0c, K2, K1), y fastest
     const float2 *Wy, *Wz;              // exp(-2 pi i j / N) of the y and z dimensions
     int K0, K1, K2, K0c;
+    int plane0;                         // first k_x plane of this launch (one workgroup per plane)
     int N1y, N2y, N1z, N2z;
     const DevState *d; DevState *dw; const float *bm0, *bm1, *bm2; float beta;
 };
@@ -623,23 +629,23 @@ template <int R> __device__ __forceinline__ void yz_pass_tw_out(float2 *P, const
 template <int R> __device__ __forceinline__ void yz_pass_tw_in(float2 *P, const float2 *W, int N, int nl, int ls, int nsub, int ss, int rs, float sgn) { yz_pass<R, 2>(P, W, N, nl, ls, nsub, ss, rs, sgn); }
 template <int R> __device__ __forceinline__ void yz_pass_plain(float2 *P, const float2 *W, int N, int nl, int ls, int nsub, int ss, int rs, float sgn) { yz_pass<R, 0>(P, W, N, nl, ls, nsub, ss, rs, sgn); }
 // all lines of one direction of the plane: element n of line l at P[l * ls + n * es]
-template <bool INVERSE>
+template <bool INVERSE, bool BIG>
 __device__ __forceinline__ void yz_lines(float2 *P, const float2 *W, int N, int N1, int N2, int nlines, int ls, int es)
 {
     if (!INVERSE) {
-        switch (N1) { MDX_DFT_CASES(yz_pass_tw_out, P, W, N, nlines, ls, N2, es, N2 * es, 1.0f) }
+        switch (N1) { MDX_DFT_CASES(yz_pass_tw_out, P, W, N, nlines, ls, N2, es, N2 * es, 1.0f) MDX_DFT_CASES_BIG(BIG, yz_pass_tw_out, P, W, N, nlines, ls, N2, es, N2 * es, 1.0f) }
         __syncthreads();
-        switch (N2) { MDX_DFT_CASES(yz_pass_plain, P, W, N, nlines, ls, N1, N2 * es, es, 1.0f) }
+        switch (N2) { MDX_DFT_CASES(yz_pass_plain, P, W, N, nlines, ls, N1, N2 * es, es, 1.0f) MDX_DFT_CASES_BIG(BIG, yz_pass_plain, P, W, N, nlines, ls, N1, N2 * es, es, 1.0f) }
     } else {
-        switch (N2) { MDX_DFT_CASES(yz_pass_plain, P, W, N, nlines, ls, N1, N2 * es, es, -1.0f) }
+        switch (N2) { MDX_DFT_CASES(yz_pass_plain, P, W, N, nlines, ls, N1, N2 * es, es, -1.0f) MDX_DFT_CASES_BIG(BIG, yz_pass_plain, P, W, N, nlines, ls, N1, N2 * es, es, -1.0f) }
         __syncthreads();
-        switch (N1) { MDX_DFT_CASES(yz_pass_tw_in, P, W, N, nlines, ls, N2, es, N2 * es, -1.0f) }
+        switch (N1) { MDX_DFT_CASES(yz_pass_tw_in, P, W, N, nlines, ls, N2, es, N2 * es, -1.0f) MDX_DFT_CASES_BIG(BIG, yz_pass_tw_in, P, W, N, nlines, ls, N2, es, N2 * es, -1.0f) }
     }
     __syncthreads();
 }
 #define MDX_YZ_THREADS 512
-template <bool ENERGY>
-__global__ __launch_bounds__(MDX_YZ_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_pme_fft_yz(FftYzArgs A)
+template <bool ENERGY, bool BIG>
+__device__ __forceinline__ void yz_plane(const FftYzArgs &A)
 {
     MDX_STAMP(A.d, 5);
     extern __shared__ float2 fsm[];
@@ -647,13 +653,13 @@ __global__ __launch_bounds__(MDX_YZ_THREADS) __attribute__((amdgpu_waves_per_eu(
     float2 *Wy = fsm, *Wz = Wy + K1, *P = Wz + K2;         // P[z * ps + y]
     for (int j = threadIdx.x; j < K1; j += blockDim.x) Wy[j] = A.Wy[j];
     for (int j = threadIdx.x; j < K2; j += blockDim.x) Wz[j] = A.Wz[j];
-    const int k0 = blockIdx.x;
+    const int k0 = A.plane0 + blockIdx.x;
     float2 *plane = A.cgrid + (size_t)k0 * K1 * K2;
     copy_batched<9, float2>(K1 * K2, [&](const int idx) { return plane[idx]; },
                             [&](const int idx, const float2 v) { const int z = idx / K1; P[z * ps + idx - z * K1] = v; });
     __syncthreads();
-    yz_lines<false>(P, Wy, K1, A.N1y, A.N2y, K2, ps, 1);
-    yz_lines<false>(P, Wz, K2, A.N1z, A.N2z, K1, 1, ps);
+    yz_lines<false, BIG>(P, Wy, K1, A.N1y, A.N2y, K2, ps, 1);
+    yz_lines<false, BIG>(P, Wz, K2, A.N1z, A.N2z, K1, 1, ps);
     {
         // influence function on position (pz, py), which holds the frequency (k1, k2) of the permuted order; energy and
         // virial as in the stand-alone solve kernel
@@ -705,13 +711,19 @@ __global__ __launch_bounds__(MDX_YZ_THREADS) __attribute__((amdgpu_waves_per_eu(
         }
         __syncthreads();
     }
-    yz_lines<true>(P, Wz, K2, A.N1z, A.N2z, K1, 1, ps);
-    yz_lines<true>(P, Wy, K1, A.N1y, A.N2y, K2, ps, 1);
+    yz_lines<true, BIG>(P, Wz, K2, A.N1z, A.N2z, K1, 1, ps);
+    yz_lines<true, BIG>(P, Wy, K1, A.N1y, A.N2y, K2, ps, 1);
     for (int idx = threadIdx.x; idx < K1 * K2; idx += blockDim.x) {
         const int z = idx / K1, y = idx - z * K1;
         plane[idx] = P[z * ps + y];
     }
 }
+// Planes up to 96 KB with radices up to 10: eight waves per SIMD (64 registers), two or more workgroups per CU beside the
+// nonbonded kernel. Larger planes (one workgroup per CU whatever its registers) and radices up to 16 take the second form.
+template <bool ENERGY>
+__global__ __launch_bounds__(MDX_YZ_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_pme_fft_yz(FftYzArgs A) { yz_plane<ENERGY, false>(A); }
+template <bool ENERGY>
+__global__ __launch_bounds__(MDX_YZ_THREADS) void k_pme_fft_yz_big(FftYzArgs A) { yz_plane<ENERGY, true>(A); }
 
 // N = N1 N2 with the smallest N1 + N2; false when a factor would exceed 32 (the library plan serves those grids)
 static bool fft_split(int N, int &N1, int &N2)
@@ -787,11 +799,14 @@ int mdx_pme_init(mdx_system *s)
     mdx_pme_free(s);
     if (s->K[0] <= 0) { s->have_pme = false; return MDX_OK; }
     const size_t nr = (size_t)s->K[0] * s->K[1] * s->K[2];
-    const size_t ncx = (size_t)s->K[2] * s->K[1] * (s->K[0] / 2 + 1);
+    // (domains that share the transform exchange the half-complex grid in equal chunks of planes: unused planes at the end)
+    const int planes = s->dd_mesh_world > 0 ? s->dd_plane_chunk * s->dd_mesh_world : s->K[0] / 2 + 1;
+    const size_t ncx = (size_t)s->K[2] * s->K[1] * planes;
     MDX_CHECK(s, hipMalloc(&s->grid, sizeof(float) * nr));
     MDX_CHECK(s, hipMalloc(&s->phi, sizeof(float) * nr));
     s->grid_clean = false;
     MDX_CHECK(s, hipMalloc(&s->cgrid, sizeof(float2) * ncx));
+    MDX_CHECK(s, hipMemset(s->cgrid, 0, sizeof(float2) * ncx));
     for (int d = 0; d < 3; d++) {
         std::vector<float> bm;
         bspline_moduli(s->K[d], bm);
@@ -817,11 +832,18 @@ int mdx_pme_init(mdx_system *s)
     {
         int a1, a2, b1, b2;
         const size_t ldsy = sizeof(float2) * ((size_t)s->K[1] + s->K[2] + (size_t)s->K[2] * (s->K[1] + 1));
-        s->fft_yz = s->own_fft && fft_split(s->K[1], a1, a2) && fft_split(s->K[2], b1, b2) && a1 >= 2 && b1 >= 2 &&
-                    a2 <= MDX_DFT_MAXR && b2 <= MDX_DFT_MAXR && ldsy <= 96 * 1024;
+        const bool split = s->own_fft && fft_split(s->K[1], a1, a2) && fft_split(s->K[2], b1, b2) && a1 >= 2 && b1 >= 2;
+        const int rmax = split ? std::max(std::max(a1, a2), std::max(b1, b2)) : 0;
+        s->fft_yz = split && rmax <= MDX_DFT_MAXR_BIG && ldsy <= (size_t)s->yz_lds_limit;
+        s->fft_yz_big = s->fft_yz && (rmax > MDX_DFT_MAXR || ldsy > 96 * 1024);
         if (s->fft_yz && ldsy > 48 * 1024) {
-            MDX_CHECK(s, hipFuncSetAttribute((const void *)k_pme_fft_yz<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsy));
-            MDX_CHECK(s, hipFuncSetAttribute((const void *)k_pme_fft_yz<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsy));
+            if (s->fft_yz_big) {
+                MDX_CHECK(s, hipFuncSetAttribute((const void *)k_pme_fft_yz_big<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsy));
+                MDX_CHECK(s, hipFuncSetAttribute((const void *)k_pme_fft_yz_big<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsy));
+            } else {
+                MDX_CHECK(s, hipFuncSetAttribute((const void *)k_pme_fft_yz<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsy));
+                MDX_CHECK(s, hipFuncSetAttribute((const void *)k_pme_fft_yz<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsy));
+            }
         }
     }
     s->have_pme = true;
@@ -878,23 +900,26 @@ int mdx_launch_pme_spread(mdx_system *s, hipStream_t st)
 
 // The PME chain on the PME stream: spreading (unless the caller has done it), transforms with the influence function,
 // gather; the gather's completion signal is the event the main stream waits for. `s->pme_part` (stage timing only)
-// restricts the chain to the spreading (1) or the gather (2).
-int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done)
+// restricts the chain to the spreading (1) or the gather (2). `stage` cuts the chain where domains that share the
+// transform exchange the half-complex grid: 1 ends behind the x forward pass, 2 is the fused y/z kernel on this domain's
+// planes, 3 the x inverse pass and the gather (0: everything).
+int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done, int stage)
 {
     if (!s->have_pme) return MDX_OK;
     const int K0 = s->K[0], K1 = s->K[1], K2 = s->K[2];
     const size_t ncx = (size_t)K2 * K1 * (K0 / 2 + 1);
     const int nb = (int)(((size_t)s->n * 16 + 255) / 256);
+    if (stage != 0 && !(s->own_fft && s->fft_yz)) { s->err = "mdx_launch_pme: this grid has no plane-wise transform to share among domains"; return MDX_ERR_UNSUPPORTED; }
     if (s->pme_part == 2) {
         hipLaunchKernelGGL(k_pme_gather, dim3(nb), dim3(256), 0, s->st_pme, s->n, (const float4 *)s->x, (const DevState *)s->d, K0, K1, K2,
                            (const float *)(s->own_fft ? s->phi : s->grid), s->f_pme);
         MDX_CHECK(s, hipGetLastError());
         return MDX_OK;
     }
-    if (!spread_done) { int rc = mdx_launch_pme_spread(s, s->st_pme); if (rc) return rc; }
+    if (stage <= 1 && !spread_done) { int rc = mdx_launch_pme_spread(s, s->st_pme); if (rc) return rc; }
     if (s->pme_part == 1) return MDX_OK;
     const float *potential = s->grid;       // the library path transforms in place
-    if (s->own_fft && !(s->dbg & 512)) {
+    if (s->own_fft && (stage != 0 || !(s->dbg & 512))) {
         FftArgs F;
         F.grid_in = s->grid; F.grid_out = s->phi; F.cgrid = s->cgrid; F.K0 = K0; F.K1 = K1; F.K2 = K2; F.K0c = K0 / 2 + 1;
         F.d = s->d; F.dw = s->d; F.bm0 = s->bmod[0]; F.bm1 = s->bmod[1]; F.bm2 = s->bmod[2]; F.beta = s->beta;
@@ -903,22 +928,34 @@ int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done)
         const int nchunk = (F.K0c + ynl - 1) / ynl;
         // one workgroup per k_x plane for the y and z passes where a plane fits into LDS and both dimensions split into
         // two factors <= 10 (mdx_debug_set key 2 bit 0x2000000 keeps the pass-per-launch form: cross-check and A/B)
-        const bool fused_yz = s->fft_yz && !(s->dbg & 0x2000000);
+        const bool fused_yz = stage != 0 || (s->fft_yz && !(s->dbg & 0x2000000));
         F.tr = fused_yz ? 1 : 0;
-        // x forward
-        F.N = K0; fft_split(K0, F.N1, F.N2); F.W = s->fftW[0]; F.nl = xnl;
-        hipLaunchKernelGGL((k_pme_fft<0, false>), dim3((K1 * K2 + F.nl - 1) / F.nl), dim3(256), lds(F), s->st_pme, F);
-        if (fused_yz) {
+        if (stage <= 1) {
+            // x forward
+            F.N = K0; fft_split(K0, F.N1, F.N2); F.W = s->fftW[0]; F.nl = xnl;
+            hipLaunchKernelGGL((k_pme_fft<0, false>), dim3((K1 * K2 + F.nl - 1) / F.nl), dim3(256), lds(F), s->st_pme, F);
+            s->grid_clean = true;
+            if (stage == 1) { MDX_CHECK(s, hipGetLastError()); return MDX_OK; }
+        }
+        if (fused_yz && stage <= 2) {
             FftYzArgs Y;
             Y.cgrid = s->cgrid; Y.Wy = s->fftW[1]; Y.Wz = s->fftW[2]; Y.K0 = K0; Y.K1 = K1; Y.K2 = K2; Y.K0c = F.K0c;
+            Y.plane0 = stage == 2 ? s->dd_plane_first : 0;
+            const int nplanes = stage == 2 ? s->dd_plane_count : F.K0c;
             fft_split(K1, Y.N1y, Y.N2y); fft_split(K2, Y.N1z, Y.N2z);
             Y.d = s->d; Y.dw = s->d; Y.bm0 = s->bmod[0]; Y.bm1 = s->bmod[1]; Y.bm2 = s->bmod[2]; Y.beta = s->beta;
             const size_t ldsy = sizeof(float2) * ((size_t)K1 + K2 + (size_t)K2 * (K1 + 1));
             // (512 threads: on energy steps the workgroups start only when the energy kernel's waves retire; with 256 threads
             // they run beside it, twice as long, and the bench is the same within its noise: 1062 against 1059 ns/day)
-            if (energy) hipLaunchKernelGGL(k_pme_fft_yz<true>, dim3(F.K0c), dim3(MDX_YZ_THREADS), ldsy, s->st_pme, Y);
-            else hipLaunchKernelGGL(k_pme_fft_yz<false>, dim3(F.K0c), dim3(MDX_YZ_THREADS), ldsy, s->st_pme, Y);
-        } else {
+            if (nplanes > 0) {
+                if (s->fft_yz_big) {
+                    if (energy) hipLaunchKernelGGL(k_pme_fft_yz_big<true>, dim3(nplanes), dim3(MDX_YZ_THREADS), ldsy, s->st_pme, Y);
+                    else hipLaunchKernelGGL(k_pme_fft_yz_big<false>, dim3(nplanes), dim3(MDX_YZ_THREADS), ldsy, s->st_pme, Y);
+                } else if (energy) hipLaunchKernelGGL(k_pme_fft_yz<true>, dim3(nplanes), dim3(MDX_YZ_THREADS), ldsy, s->st_pme, Y);
+                else hipLaunchKernelGGL(k_pme_fft_yz<false>, dim3(nplanes), dim3(MDX_YZ_THREADS), ldsy, s->st_pme, Y);
+            }
+            if (stage == 2) { MDX_CHECK(s, hipGetLastError()); return MDX_OK; }
+        } else if (stage == 0) {
             // y forward
             F.N = K1; fft_split(K1, F.N1, F.N2); F.W = s->fftW[1]; F.nl = ynl;
             hipLaunchKernelGGL((k_pme_fft<1, false>), dim3(K2 * nchunk), dim3(256), lds(F), s->st_pme, F);
@@ -933,7 +970,6 @@ int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done)
         // x inverse
         F.N = K0; fft_split(K0, F.N1, F.N2); F.W = s->fftW[0]; F.nl = xnl;
         hipLaunchKernelGGL((k_pme_fft<4, false>), dim3((K1 * K2 + F.nl - 1) / F.nl), dim3(256), lds(F), s->st_pme, F);
-        s->grid_clean = true;
         potential = s->phi;
     } else {
         hipfftSetStream(s->plan_r2c, s->st_pme); hipfftSetStream(s->plan_c2r, s->st_pme);

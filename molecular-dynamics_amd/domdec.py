@@ -17,8 +17,12 @@ Scheme (see csrc/domdec.hip for the device side):
 * Every other step: the positions of those atoms are packed on the device, exchanged point to point
   (one batched send/recv group: `ncclSend`/`ncclRecv` under NCCL) and scattered into the halo slots.
   Forces are not sent back: a pair across a boundary is evaluated by both owners, each keeping its own half.
-* PME: every rank spreads its home charges on a full-size grid, the grids are summed with one all-reduce,
-  and every rank solves the whole mesh problem and gathers forces for its home atoms.
+* PME: every rank spreads its home charges on a full-size grid and transforms it along x (a sum over ranks commutes
+  with that pass); the half-complex grids are reduce-scattered by chunks of k_x planes, every rank does the y and z
+  transforms and the influence function on its own planes (each plane is a self-contained problem), the planes are
+  all-gathered, and every rank transforms back along x and gathers forces for its home atoms (`mesh="slabs"`).
+  `mesh="replicated"`, and any PME grid whose planes the fused plane kernel does not take, keeps the first scheme: the
+  real-space grids are summed with one all-reduce and every rank solves the whole mesh problem.
 * Thermostat, barostat (C-rescale or Parrinello-Rahman), dispersion correction and centre-of-mass removal act on the
   whole system: the domains sum a few scalars per coupling step and apply the same factors (`DecomposedWater`).
 
@@ -176,6 +180,7 @@ class Transport:
         # host-synchronised path is the default and MDX_DD_ORDERED=1 opts in.
         self.ordered = dist.is_initialized() and not self.staged and (self.world == 1 or os.environ.get("MDX_DD_ORDERED") == "1")
         self.force = self.ordered and bool(os.environ.get("MDX_DD_FORCE_COLLECTIVES"))
+        self.poison = False
 
     def all_gather(self, t: torch.Tensor):
         if self.world == 1:
@@ -194,6 +199,33 @@ class Transport:
             t.copy_(h)
         else:
             dist.all_reduce(t, group=self.group)
+        return t
+
+    def reduce_scatter_sum_(self, t: torch.Tensor):
+        """t: (world, chunk) contiguous. On return t[rank] holds the sum of every rank's t[rank]; the other rows are
+        undefined (with `poison` they are filled with NaN, so that a reader of a row it does not own shows up)."""
+        if self.world == 1 and not self.force:
+            return t
+        if self.staged:
+            h = t.to("cpu", copy=True)
+            dist.all_reduce(h, group=self.group)        # (gloo has no reduce-scatter)
+            if self.poison:
+                t.fill_(float("nan"))
+            t[self.rank].copy_(h[self.rank])
+        else:
+            dist.reduce_scatter_tensor(t[self.rank], t, group=self.group)
+        return t
+
+    def all_gather_rows_(self, t: torch.Tensor):
+        """t: (world, chunk) contiguous. On return row r of every rank's t is rank r's row r."""
+        if self.world == 1 and not self.force:
+            return t
+        if self.staged:
+            out = [torch.empty(t.shape[1:], dtype=t.dtype) for _ in range(self.world)]
+            dist.all_gather(out, t[self.rank].cpu().contiguous(), group=self.group)
+            t.copy_(torch.stack(out))
+        else:
+            dist.all_gather_into_tensor(t, t[self.rank], group=self.group)
         return t
 
     def exchange(self, send, recv):
@@ -263,6 +295,7 @@ class ThreadTransport:
         self.in_process = True
         self.serial = hub.exclusive     # DecomposedWater drains its handle before it hands the GPU over
         self.stream = None              # torch stream of this thread's collectives (set by DecomposedWater)
+        self.poison = True              # rows a reduce-scatter leaves undefined are filled with NaN
 
     def _meet(self):
         """All work of this thread complete, then wait for the others (with the lock handed over, if there is one)."""
@@ -292,6 +325,25 @@ class ThreadTransport:
         total = torch.stack(list(self.hub.slots)).sum(0)
         self._meet()
         t.copy_(total)
+        return t
+
+    def reduce_scatter_sum_(self, t):
+        self.hub.slots[self.rank] = t
+        self._meet()
+        mine = torch.stack([s[self.rank] for s in self.hub.slots]).sum(0)
+        self._meet()
+        if self.poison:
+            t.fill_(float("nan"))
+        t[self.rank].copy_(mine)
+        return t
+
+    def all_gather_rows_(self, t):
+        self.hub.slots[self.rank] = t
+        self._meet()
+        rows = [self.hub.slots[r][r].clone() for r in range(self.world) if r != self.rank]
+        self._meet()
+        for r, row in zip([r for r in range(self.world) if r != self.rank], rows):
+            t[r].copy_(row)
         return t
 
     def exchange(self, send, recv):
@@ -337,7 +389,7 @@ class DecomposedWater:
                  rlist: float | None = None, seed: int = 1, group=None, dims=None, nstcalcenergy: int = 0,
                  transport=None, global_coupling: bool = True, nstcomm: int = 0, pcoupl: str | None = None, tau_p: float = 2.0,
                  ref_p: float = 1.0, compressibility: float = 4.5e-5, nstpcouple: int = 10, dispcorr: int = 0,
-                 migration: bool = True):
+                 migration: bool = True, mesh: str = "slabs"):
         """global_coupling: one V-rescale factor for the whole system from the kinetic energy summed over the domains
         (every domain draws it from the same random stream); False: every domain is its own thermostat group.
         nstcomm > 0: centre-of-mass motion of the whole system removed every nstcomm steps.
@@ -347,6 +399,10 @@ class DecomposedWater:
         pressure.
         migration: the partition is renewed by sending the molecules that left a brick, and the halo, to the ranks that need
         them (`migrate`); False gathers every molecule on every rank each pair-list lifetime (the cross-check).
+        mesh: "slabs" shares the mesh transform among the ranks (every rank transforms its own k_x planes of the
+        half-complex grid between a reduce-scatter and an all-gather); "replicated" sums the real-space charge grids with
+        one all-reduce and lets every rank solve the whole mesh problem (also taken when the PME grid's planes do not fit
+        the plane kernel: `self.mesh` tells which is in use).
         dispcorr: 1 adds the analytic long-range dispersion correction of the whole system (`DispCorr = Ener`) to the
         energies, 2 (`EnerPres`, /root/reference/mdp/production.mdp:44) also to the pressure, the coupled one included: it
         depends on the atom count, the volume and <C6> of the whole system only, so every rank evaluates it itself."""
@@ -407,10 +463,19 @@ class DecomposedWater:
         self.thermostat = ref_t is not None
         self.global_coupling = bool(global_coupling)
         self.nsttcouple, self.nstcomm, self.nstcalcenergy = int(nsttcouple), int(nstcomm), int(nstcalcenergy)
-        # the reciprocal-space energy is the same on every domain: the first one reports it
-        self.engine.dd_set_roles(self.rank == 0, not (self.global_coupling and self.thermostat))
-        gp, gn = self.engine.dd_grid()
-        self.grid_t = torch.as_tensor(_DevArray(gp, (gn,)), device=self.dev)
+        if mesh not in ("slabs", "replicated"):
+            raise ValueError("mesh: slabs or replicated")
+        self.mesh = "slabs" if mesh == "slabs" and self.engine.dd_mesh_slabs(self.world, self.rank) else "replicated"
+        if self.mesh == "slabs":
+            # every domain reports the reciprocal-space energy of its own planes
+            self.engine.dd_set_roles(True, not (self.global_coupling and self.thermostat))
+            cp, chunk, plane = self.engine.dd_cgrid()
+            self.cgrid_t = torch.as_tensor(_DevArray(cp, (self.world, chunk * plane * 2)), device=self.dev)
+        else:
+            # the reciprocal-space energy is the same on every domain: the first one reports it
+            self.engine.dd_set_roles(self.rank == 0, not (self.global_coupling and self.thermostat))
+            gp, gn = self.engine.dd_grid()
+            self.grid_t = torch.as_tensor(_DevArray(gp, (gn,)), device=self.dev)
         ep, cp = self.engine.dd_scalars()
         self.ekinh_t = torch.as_tensor(_DevArray(ep, (8,), "<f8"), device=self.dev)
         self.com_t = torch.as_tensor(_DevArray(cp, (4,), "<f8"), device=self.dev)
@@ -557,10 +622,18 @@ class DecomposedWater:
                 say("repartition"); self.repartition()
             elif self.steps_since_partition > 0:
                 say("halo refresh"); self._refresh_halo()
+            slabs = self.mesh == "slabs"
             if self.ordered:
                 say("begin"); self.engine.dd_step_begin()
-                with torch.cuda.stream(self.st_pme):        # behind the spreading, ahead of the transforms
-                    say("grid sum"); self.tr.all_reduce_sum_(self.grid_t)
+                with torch.cuda.stream(self.st_pme):        # behind the spreading (slabs: the x pass), ahead of the transforms
+                    if slabs:
+                        say("plane sums"); self.tr.reduce_scatter_sum_(self.cgrid_t)
+                    else:
+                        say("grid sum"); self.tr.all_reduce_sum_(self.grid_t)
+                if slabs:
+                    say("mid"); self.engine.dd_step_mid()
+                    with torch.cuda.stream(self.st_pme):    # behind this rank's planes, ahead of the x pass back
+                        say("plane gather"); self.tr.all_gather_rows_(self.cgrid_t)
                 say("end"); self.engine.dd_step_end()
             else:
                 with self._exclusive():
@@ -568,8 +641,19 @@ class DecomposedWater:
                     if self.world > 1:
                         say("wait spread"); self.engine.dd_wait_spread()
                 if self.world > 1:
-                    say("grid sum"); self.tr.all_reduce_sum_(self.grid_t)
+                    if slabs:
+                        say("plane sums"); self.tr.reduce_scatter_sum_(self.cgrid_t)
+                    else:
+                        say("grid sum"); self.tr.all_reduce_sum_(self.grid_t)
                     torch.cuda.synchronize(self.dev)
+                if slabs:
+                    with self._exclusive():
+                        say("mid"); self.engine.dd_step_mid()
+                        if self.world > 1:
+                            self.engine.dd_wait_spread()
+                    if self.world > 1:
+                        say("plane gather"); self.tr.all_gather_rows_(self.cgrid_t)
+                        torch.cuda.synchronize(self.dev)
                 with self._exclusive():
                     say("end"); self.engine.dd_step_end()
             done = self.nsteps_done + 1

@@ -34,6 +34,7 @@ SYMBOLS = [
     "mdx_synchronize", "mdx_get_list_stats", "mdx_pop_energy_frames", "mdx_pop_pull_records",
     "mdx_enable_kernel_timing", "mdx_get_kernel_timing", "mdx_debug_time_nonbonded", "mdx_debug_set", "mdx_debug_wave_times", "mdx_debug_stamps",
     "mdx_dd_load", "mdx_dd_pack", "mdx_dd_unpack", "mdx_dd_step_begin", "mdx_dd_wait_spread", "mdx_dd_step_end", "mdx_dd_grid",
+    "mdx_dd_mesh_slabs", "mdx_dd_cgrid", "mdx_dd_step_mid",
     "mdx_dd_stream_sync", "mdx_dd_state_pointers", "mdx_dd_streams", "mdx_dd_set_roles", "mdx_dd_scalars", "mdx_dd_tcouple", "mdx_dd_kinetic", "mdx_dd_com", "mdx_dd_pressure", "mdx_dd_pcouple",
     "mdx_debug_time_stage", "mdx_set_step", "mdx_generate_velocities", "mdx_constrain_start", "mdx_minimize",
     "mdx_frame_ring", "mdx_capture_frame", "mdx_frame_wait", "mdx_capture_frame_xtc", "mdx_frame_wait_xtc",
@@ -131,6 +132,8 @@ def load_library(path: str | None = None):
     L.mdx_dd_unpack.argtypes = [vp, c_int, c_int, vp]
     L.mdx_dd_step_begin.argtypes = [vp]; L.mdx_dd_wait_spread.argtypes = [vp]; L.mdx_dd_step_end.argtypes = [vp]
     L.mdx_dd_grid.argtypes = [vp, ctypes.POINTER(vp), llp]
+    L.mdx_dd_mesh_slabs.argtypes = [vp, c_int, c_int]; L.mdx_dd_step_mid.argtypes = [vp]
+    L.mdx_dd_cgrid.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(c_int), llp]
     L.mdx_dd_stream_sync.argtypes = [vp]
     L.mdx_dd_state_pointers.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
     L.mdx_dd_streams.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
@@ -609,6 +612,25 @@ class Engine:
         p = ctypes.c_void_p(0); n = ctypes.c_longlong(0)
         self._call("mdx_dd_grid", ctypes.byref(p), ctypes.byref(n))
         return p.value, n.value
+
+    def dd_mesh_slabs(self, world, rank):
+        """Share the mesh transform among `world` domains (this one transforms chunk `rank` of the half-complex grid's
+        planes). False when the PME grid has no plane-wise transform: the caller keeps the sum of the real-space grids."""
+        rc = self.lib.mdx_dd_mesh_slabs(self.h, int(world), int(rank))
+        if rc == -5:        # MDX_ERR_UNSUPPORTED
+            return False
+        if rc != 0:
+            raise MdxError(f"mdx_dd_mesh_slabs failed ({rc}): " + self.lib.mdx_last_error(self.h).decode())
+        return True
+
+    def dd_cgrid(self):
+        """(device pointer of the half-complex grid, planes per domain, complex values per plane)."""
+        p = ctypes.c_void_p(0); c = ctypes.c_int(0); n = ctypes.c_longlong(0)
+        self._call("mdx_dd_cgrid", ctypes.byref(p), ctypes.byref(c), ctypes.byref(n))
+        return p.value, c.value, n.value
+
+    def dd_step_mid(self):
+        self._call("mdx_dd_step_mid")
 
     def dd_streams(self):
         """(main stream, PME stream) as raw hipStream_t values (for torch.cuda.ExternalStream)."""

@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 
-def decomposed(world, nst, rest, d, migration=True):
+def decomposed(world, nst, rest, d, migration=True, mesh="slabs"):
     import mdx
     from mdx import synth, domdec
     hub = domdec.ThreadTransport.Hub(world, exclusive=bool(os.environ.get("MDX_DD_EXCLUSIVE")))
@@ -23,8 +23,8 @@ def decomposed(world, nst, rest, d, migration=True):
         if rest:
             s.v = np.zeros_like(s.v)
         dd = domdec.DecomposedWater(s, device=0, rc=1.0, dt=0.002, nstlist=10, ref_t=None, rlist=1.1, transport=transport,
-                                    migration=migration)
-        info = dict(dims=dd.dims, home=dd.n_home, halo=dd.n_halo, cap=dd.cap)
+                                    migration=migration, mesh=mesh)
+        info = dict(dims=dd.dims, home=dd.n_home, halo=dd.n_halo, cap=dd.cap, mesh=dd.mesh)
         dd.step(nst); dd.synchronize()
         info["list_tiles"] = dd.engine.list_stats()["cluster_pairs"]
         x, v = dd.gather_state()
@@ -47,7 +47,7 @@ def coupled(world, nst, d):
         e, vir, pres = dd.energies()
         x, v = dd.gather_state()
         dd.close()
-        return dict(e=e, vir=vir, pres=pres, v=v)
+        return dict(e=e, vir=vir, pres=pres, v=v, mesh=dd.mesh)
     o = hub.run(rank_main)[0]
     s = synth.water_box(d=d)
     e = eng.Engine(s, tc_groups=["System"], ref_t=[300.0], tau_t=[0.1], nsttcouple=10, nstcalcenergy=10, nstcomm=10, seed=7, **kw)
@@ -59,7 +59,7 @@ def coupled(world, nst, d):
                 vir_max_diff=float(np.abs(o["vir"] - virr).max()), vir_scale=float(np.abs(virr).max()),
                 pres_max_diff=float(np.abs(o["pres"] - presr).max()),
                 dv_rel_rms=float(np.sqrt(((o["v"] - vr) ** 2).mean() / (vr ** 2).mean())),
-                com_v=[float(c) for c in (s.mass[:, None] * o["v"]).sum(0) / s.mass.sum()])
+                com_v=[float(c) for c in (s.mass[:, None] * o["v"]).sum(0) / s.mass.sum()], mesh=o["mesh"])
 
 
 def coupled_npt(world, nst, d, kind="c-rescale"):
@@ -102,9 +102,10 @@ def main(world=2, steps=12, d=7.0):
     import mdx
     from mdx import synth, engine as eng
     res = {"world": world, "steps": steps}
-    # ("traj_gather": the partition renewed by gathering every molecule on every rank instead of by migration)
+    # ("traj_gather": the partition renewed by gathering every molecule on every rank instead of by migration, and the
+    # real-space charge grids summed on every rank instead of the mesh transform shared by planes)
     for label, nst, rest in (("rest", 1, True), ("traj", steps, False), ("traj_gather", steps, False)):
-        o = decomposed(world, nst, rest, d, migration=label != "traj_gather")
+        o = decomposed(world, nst, rest, d, migration=label != "traj_gather", mesh="replicated" if label == "traj_gather" else "slabs")
         s = synth.water_box(d=d)
         if rest:
             s.v = np.zeros_like(s.v)

@@ -120,6 +120,15 @@ def _exchange_worker(rank, world, port):
     g = torch.full((16,), float(rank + 1))
     tr.all_reduce_sum_(g)
     assert torch.equal(g, torch.full((16,), 3.0))
+    # the collectives of the shared mesh transform: row r summed onto rank r, then every row back from its owner
+    t = torch.arange(10.0).reshape(2, 5) * (rank + 1)
+    tr.poison = True
+    tr.reduce_scatter_sum_(t)
+    assert torch.equal(t[rank], torch.arange(10.0).reshape(2, 5)[rank] * 3) and torch.isnan(t[1 - rank]).all()
+    t[rank] += 100.0 * rank
+    tr.all_gather_rows_(t)
+    want = torch.arange(10.0).reshape(2, 5) * 3; want[1] += 100.0
+    assert torch.equal(t, want)
     dist.destroy_process_group()
 
 
@@ -209,3 +218,41 @@ def test_migration_eight_ranks_in_process():
     out = hub.run(body)
     assert sum(n for n, _ in out) == x.shape[0]
     assert sum(m for _, m in out) > 0, "the displacement moved no molecule across a brick face: the test tests nothing"
+
+
+# ------------------------------------------------------------------------------------------------ shared mesh transform
+def test_mesh_transform_shared_by_planes_in_process():
+    """The scheme of the decomposed PME step on CPU tensors, eight ranks in one process: every rank transforms its own
+    partial charge grid along x, the half-complex grids are reduce-scattered by chunks of k_x planes (11 planes over 8
+    ranks: chunks of 2, the last ranks own one plane and none), every rank convolves its planes in y and z, the planes are
+    all-gathered and transformed back along x. Against the convolution of the summed grid done in one piece."""
+    import numpy as np
+    K0, K1, K2 = 20, 6, 8
+    world = 8
+    K0c = K0 // 2 + 1
+    chunk = -(-K0c // world)
+    rng = np.random.default_rng(5)
+    parts = rng.standard_normal((world, K2, K1, K0)).astype(np.float32)
+    infl = rng.random((K0c, K2, K1)).astype(np.float32)                     # a multiplier per (k_x, k_z, k_y)
+    whole = np.fft.irfftn(np.fft.rfftn(parts.astype(np.float64).sum(0), axes=(0, 1, 2)) * infl.transpose(1, 2, 0), s=(K2, K1, K0), axes=(0, 1, 2))
+    hub = domdec.ThreadTransport.Hub(world)
+
+    def body(rank, tr):
+        fx = np.fft.rfft(parts[rank].astype(np.float64), axis=2)               # (K2, K1, K0c): x pass on the rank's own grid
+        planes = np.zeros((world * chunk, K2, K1), dtype=np.complex128)
+        planes[:K0c] = fx.transpose(2, 0, 1)                                   # plane-major, as the device stores it
+        t = torch.from_numpy(planes.view(np.float64).reshape(world, -1).copy())
+        tr.reduce_scatter_sum_(t)
+        assert bool(torch.isnan(t[(rank + 1) % world]).all())                  # only the own chunk is defined now
+        own = t[rank].numpy().view(np.complex128).reshape(chunk, K2, K1)
+        first = rank * chunk
+        n_own = max(0, min(K0c, first + chunk) - first)
+        for p in range(n_own):
+            own[p] = np.fft.ifft2(np.fft.fft2(own[p]) * infl[first + p])
+        tr.all_gather_rows_(t)
+        back = t.numpy().view(np.complex128).reshape(world * chunk, K2, K1)[:K0c]
+        return np.fft.irfft(back.transpose(1, 2, 0), n=K0, axis=2), n_own
+    out = hub.run(body)
+    assert sorted(n for _, n in out) == [0, 0, 1, 2, 2, 2, 2, 2]
+    for phi, _ in out:
+        assert np.abs(phi - whole).max() < 1e-10 * np.abs(whole).max()

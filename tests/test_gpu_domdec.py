@@ -25,6 +25,10 @@ def test_domains_match_single_handle(world, box):
     res = _run(world, box)
     part = res["traj"]["partition"]
     assert part["halo"] > 0 and part["home"] > 0
+    # the mesh transform is shared by planes of the half-complex grid (reduce-scatter, own planes, all-gather; the
+    # in-process transport fills the planes a domain does not own with NaN in between), energies included; the
+    # "traj_gather" run below keeps the summed real-space grids
+    assert part["mesh"] == "slabs" and res["coupled"]["mesh"] == "slabs" and res["traj_gather"]["partition"]["mesh"] == "replicated", res
     # forces through the whole decomposed path (halo exchange, summed charge grid): one step from rest. The same
     # measure between the one-domain decomposed path and the plain handle, which differ in atom order and padding
     # only, is 8e-6 (float32 evaluation order through the constrained update); two domains measure 1.0e-5.

@@ -16,11 +16,16 @@ def relrms(a, b):
     return float(np.sqrt(((a - b) ** 2).sum() / (b ** 2).sum()))
 
 
-# (the last grid: a k_x plane of 54 KB, above the default limit of dynamic LDS per workgroup; (22, 26, 24): 26 = 2 x 13 has a
-# factor above 10, so the y and z passes take one launch each)
-@pytest.mark.parametrize("grid", [(24, 24, 16), (28, 20, 18), (21, 25, 27), (32, 36, 40), (30, 42, 14), (49, 24, 35), (22, 26, 24), (30, 90, 72)])
-def test_own_transform_matches_oracle_and_library(grid, small_water):
+# ((30, 90, 72): a k_x plane of 54 KB, above the default limit of dynamic LDS per workgroup; (22, 26, 24): 26 = 2 x 13 has a
+# factor above 10, which the plane kernel takes in its second form (radices up to 16); (22, 34, 24): 34 = 2 x 17 has none
+# the plane kernel takes, so the y and z passes run one launch each; (20, 160, 112): the planes of the million-atom box's
+# grid, 143 KB with factors 10 x 16 and 8 x 14, in the plane kernel's second form with the LDS limit raised for it)
+@pytest.mark.parametrize("grid", [(24, 24, 16), (28, 20, 18), (21, 25, 27), (32, 36, 40), (30, 42, 14), (49, 24, 35), (22, 26, 24), (22, 34, 24),
+                                  (30, 90, 72), (20, 160, 112)])
+def test_own_transform_matches_oracle_and_library(grid, small_water, monkeypatch):
     s = small_water
+    if grid == (20, 160, 112):
+        monkeypatch.setenv("MDX_YZ_LDS_KB", "150")
     e = eng.Engine(s, rc=1.0, nstcalcenergy=1, grid=grid)
     try:
         f_own, en_own = e.compute(eng.F_PME)
