@@ -199,10 +199,13 @@ int mdx_minimize(mdx_system *sys, long long nsteps, double emtol, double emstep,
                  void (*progress)(long long step, double epot, double fmax, double stepsize));
 /* Trajectory output cadence (`nstxout`, `nstvout`, `nstxout-compressed`,
  * /root/reference/mdp/production.mdp:7-12): a ring of pinned host slots. mdx_capture_frame
- * enqueues the copy of the current x (and v) and box behind the steps already enqueued and
- * returns at once; mdx_frame_wait blocks until that copy has landed and may be called from a
- * writer thread while the stepping thread keeps enqueuing. Pointers stay valid until the slot
- * is captured into again. */
+ * takes the state behind the steps already enqueued (x, v if wanted, box) and returns at once: the
+ * kernels that write it into the slot's pinned memory are launched by the next mdx_step, beside
+ * that step's force kernels (or by mdx_synchronize, by any call that replaces the state, or by a
+ * wait that no step has served within 2 ms). mdx_frame_wait blocks until the frame has landed and
+ * may be called from a writer thread while the stepping thread keeps enqueuing. Pointers stay valid
+ * until the slot is captured into again; a slot cannot be captured into twice without a step, a
+ * synchronisation or a wait in between (MDX_ERR_ARG). */
 int mdx_frame_ring(mdx_system *sys, int nslots);
 int mdx_capture_frame(mdx_system *sys, int slot, int want_v);
 int mdx_frame_wait(mdx_system *sys, int slot, const float **x, const float **v, double *box9,

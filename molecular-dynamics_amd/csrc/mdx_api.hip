@@ -576,6 +576,7 @@ extern "C" int mdx_set_state(mdx_system *s, const float *x, const float *v, cons
     ARG_CHECK(s, x && box9, "mdx_set_state: null pointer");
     HostAtoms &ha = host_atoms(s);
     ARG_CHECK(s, (int)ha.q.size() == s->n, "mdx_set_state: call mdx_set_atoms first");
+    if (s->frame_ring) { const int rcf = mdx_frames_flush(s, s->stream); if (rcf) return rcf; }       // captured frames read the state about to be replaced
     int rc = upload_box(s, box9); if (rc) return rc;
     const int n = s->n;
     std::vector<float4> hx(n), hv(n);
@@ -618,6 +619,7 @@ extern "C" int mdx_set_state_device(mdx_system *s, const void *xd, const void *v
     ARG_CHECK(s, xd && box9, "mdx_set_state_device: null pointer");
     HostAtoms &ha = host_atoms(s);
     ARG_CHECK(s, (int)ha.q.size() == s->n, "mdx_set_state_device: call mdx_set_atoms first");
+    if (s->frame_ring) { const int rcf = mdx_frames_flush(s, s->stream); if (rcf) return rcf; }       // captured frames read the state about to be replaced
     int rc = upload_box(s, box9); if (rc) return rc;
     const int n = s->n, nb = (n + 255) / 256;
     // charges / inverse masses ride in the .w lanes: (re)write them from the host copies
@@ -637,6 +639,7 @@ extern "C" int mdx_set_state_device(mdx_system *s, const void *xd, const void *v
 
 static int sync_and_check(mdx_system *s)
 {
+    if (s->frame_ring) { const int rc = mdx_frames_flush(s, s->stream); if (rc) return rc; }
     // (a pruning launch is the one piece of work that no step joins into the main stream: it ends on the bonded stream)
     if (s->prune_pending) { MDX_CHECK(s, hipStreamSynchronize(s->st_bond)); s->prune_pending = false; }
     // (thermostat factors still to be drawn from the last update's kinetic-energy sums: normally the next step's bonded stream does it)
@@ -968,6 +971,9 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
         if (phase == 1) return MDX_OK;
     }
     if (phase == 2) if ((rc = slabs ? mdx_launch_pme(s, false, true, 3) : mdx_launch_pme(s, need_vir && s->dd_mesh_energy, true))) return rc;
+    // trajectory frames captured ahead of this step: written to their pinned slots on the bonded stream, beside the nonbonded
+    // kernel and ahead of the marker the update waits for (the update changes the box, and the next one the captured buffers)
+    if (s->frame_ring) if ((rc = mdx_frames_flush(s, s->st_bond))) return rc;
     if ((rc = mdx_join(s))) return rc;
     if (do_prune) {
         // Beside this step's nonbonded kernel (which still reads the list of the last prune, or on a search step the outer

@@ -304,6 +304,7 @@ int mdx_fused_plan(mdx_system *s);
 int mdx_launch_update_fused(mdx_system *s, bool do_tc, bool do_pr, bool write_sorted, bool fork_signal, bool with_ke = false);
 int mdx_launch_tcouple_fold(mdx_system *s, hipStream_t st, long long step);
 void mdx_frames_free(mdx_system *s);
+int mdx_frames_flush(mdx_system *s, hipStream_t st);      // launch the kernels of captured trajectory frames on `st` (behind what it holds)
 int mdx_launch_ke(mdx_system *s, bool old_slot, bool tensor, hipStream_t st = nullptr, bool tc_slot = false);
 int mdx_launch_comm_phase(mdx_system *s, int phase);
 int mdx_launch_clear(mdx_system *s, bool energies, bool ekin_new, bool ekin_old);

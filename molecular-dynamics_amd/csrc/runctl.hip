@@ -6,7 +6,10 @@
 // (/root/reference/mdp/em_complex.mdp:3-6) and the output cadence keys `nstxout`,
 // `nstvout`, `nstxout-compressed` (/root/reference/mdp/production.mdp:7-12) switch on in gmx mdrun.
 #include "mdx_internal.h"
+#include <chrono>
 #include <climits>
+#include <mutex>
+#include <thread>
 #include <hip/hip_ext.h>
 #include <algorithm>
 #include <cmath>
@@ -57,6 +60,7 @@ __global__ __launch_bounds__(256) void k_scale_vel_to(int n, float4 *__restrict_
 
 extern "C" int mdx_generate_velocities(mdx_system *s, double temperature, unsigned long long seed)
 {
+    if (s->frame_ring) { const int rc = mdx_frames_flush(s, s->stream); if (rc) return rc; }
     (void)hipSetDevice(s->device);
     ARG_CHECK(s, temperature >= 0.0, "mdx_generate_velocities: negative temperature");
     const int n = s->n, nb = (n + 255) / 256;
@@ -86,6 +90,7 @@ __global__ __launch_bounds__(256) void k_copy_pos(int n, const float4 *__restric
 
 extern "C" int mdx_constrain_start(mdx_system *s)
 {
+    if (s->frame_ring) { const int rc = mdx_frames_flush(s, s->stream); if (rc) return rc; }
     (void)hipSetDevice(s->device);
     if (s->nsettle == 0 && s->ncomp == 0) return MDX_OK;
     const int n = s->n, nb = (n + 255) / 256;
@@ -152,6 +157,7 @@ extern "C" int mdx_minimize(mdx_system *s, long long nsteps, double emtol, doubl
 {
     (void)hipSetDevice(s->device);
     ARG_CHECK(s, nsteps >= 0 && emstep > 0.0, "mdx_minimize: nsteps >= 0 and emstep > 0 required");
+    if (s->frame_ring) { const int rcf = mdx_frames_flush(s, s->stream); if (rcf) return rcf; }
     const int n = s->n, nb = (n + 255) / 256;
     const unsigned terms = MDX_F_ALL & ~MDX_F_PULL;
     float *d_fmax = nullptr;
@@ -211,12 +217,17 @@ extern "C" int mdx_minimize(mdx_system *s, long long nsteps, double emtol, doubl
 }
 
 // ---------------------------------------------------------------- trajectory frames
-// A ring of pinned host slots. A capture enqueues unpack kernels into a per-slot device staging area
-// on the main stream; the device-to-host copies run on the bonded stream (idle between two steps and
-// with slack inside a step), released by the completion signal of the last unpack kernel, so the main
-// stream never waits for the DMA. A stream of their own would be the fourth of the process: with four
-// hardware queues per process it would share a queue with a compute stream and stall it (measured:
-// +130 us per step). A writer thread waits for the slot's event and encodes the frame.
+// A ring of pinned host slots. A capture notes the slot and the state buffers of the moment; the kernels that unpack (or
+// round) the state are launched by the next step on its bonded stream, behind the bonded kernel and ahead of the marker the
+// update waits for, and write straight into the slot's pinned memory. On the main stream a capture costs nothing, and no
+// copy follows: a device-to-host copy is a kernel of the runtime's (30 us for 1.7 MB, on compute units, beside the energy
+// step's constraint kernel), and in front of it the staging kernel and its hand-over held the main stream for 12 us per frame.
+// The buffers a capture notes stay as they are through the next step: positions and velocities are double-buffered (the
+// step's update writes the other pair), the box changes only in the update. Anything else that rewrites the state
+// launches the pending captures first (mdx_frames_flush). A stream of their own for the frames would be the fourth of the
+// process: with four hardware queues per process it shares a queue with a compute stream and stalls it (measured twice:
+// +130 us per step in an early form of the step, 170 against 162 us per step in the present one).
+// A writer thread waits for the slot's event and encodes the frame.
 __global__ __launch_bounds__(256) void k_unpack3(int n, const float4 *__restrict__ a, float *__restrict__ out,
                                                  const double *__restrict__ boxd, double *__restrict__ box_out)
 {
@@ -290,8 +301,13 @@ __global__ __launch_bounds__(256) void k_frame_quantize(int n, const float4 *__r
     }
 }
 
-struct FrameSlot { float *x = nullptr, *v = nullptr; double *box = nullptr; int *stats = nullptr; hipEvent_t ev = nullptr, ev_staged = nullptr; long long step = -1; int has_v = 0; int quantized = 0; };
-struct FrameRing { std::vector<FrameSlot> slots; float *d_stage = nullptr; double *d_box = nullptr; int *d_stats = nullptr; };
+struct FrameSlot { float *x = nullptr, *v = nullptr; double *box = nullptr; int *stats = nullptr; hipEvent_t ev = nullptr; long long step = -1; int has_v = 0; int quantized = 0;
+                   bool enqueued = true; const float4 *src_x = nullptr, *src_v = nullptr; float precision = 0.0f; };
+// A slot's positions (or xtc integers), statistics and box are one pinned block:
+// [x: 3 n words | pad to 8 bytes | stats: 8 MDX_FRAME_WGS ints | box: 9 doubles].
+// `pending`: slots captured whose kernels are not launched yet; `lock` guards it and the slots' `enqueued` flags (the stepping
+// thread launches them, a writer thread waiting for a frame looks and, if no step comes, launches them itself).
+struct FrameRing { std::vector<FrameSlot> slots; size_t x_words = 0, slot_words = 0; std::vector<int> pending; std::mutex lock; };
 static FrameRing *ring_of(mdx_system *s) { return (FrameRing *)s->frame_ring; }
 
 void mdx_frames_free(mdx_system *s)
@@ -299,16 +315,10 @@ void mdx_frames_free(mdx_system *s)
     FrameRing *r = ring_of(s);
     if (!r) return;
     for (FrameSlot &f : r->slots) {
-        if (f.x) (void)hipHostFree(f.x);
+        if (f.x) (void)hipHostFree(f.x);          // (statistics and box are part of this block)
         if (f.v) (void)hipHostFree(f.v);
-        if (f.box) (void)hipHostFree(f.box);
-        if (f.stats) (void)hipHostFree(f.stats);
         if (f.ev) (void)hipEventDestroy(f.ev);
-        if (f.ev_staged) (void)hipEventDestroy(f.ev_staged);
     }
-    if (r->d_stage) (void)hipFree(r->d_stage);
-    if (r->d_box) (void)hipFree(r->d_box);
-    if (r->d_stats) (void)hipFree(r->d_stats);
     delete r;
     s->frame_ring = nullptr;
 }
@@ -321,20 +331,45 @@ extern "C" int mdx_frame_ring(mdx_system *s, int nslots)
     FrameRing *r = new FrameRing();
     s->frame_ring = r;
     r->slots.resize(nslots);
-    const size_t bytes = sizeof(float) * 3 * (size_t)s->n;
+    const size_t cnt = 3 * (size_t)s->n;
+    r->x_words = (cnt + 1) & ~(size_t)1;                                   // statistics and box start on an 8-byte boundary
+    r->slot_words = r->x_words + 8 * MDX_FRAME_WGS + 18;
     for (FrameSlot &f : r->slots) {
-        MDX_CHECK(s, hipHostMalloc((void **)&f.x, bytes, hipHostMallocDefault));
-        MDX_CHECK(s, hipHostMalloc((void **)&f.v, bytes, hipHostMallocDefault));
-        MDX_CHECK(s, hipHostMalloc((void **)&f.box, sizeof(double) * 9, hipHostMallocDefault));
-        MDX_CHECK(s, hipHostMalloc((void **)&f.stats, sizeof(int) * 8 * MDX_FRAME_WGS, hipHostMallocDefault));
+        MDX_CHECK(s, hipHostMalloc((void **)&f.x, sizeof(float) * r->slot_words, hipHostMallocDefault));
+        MDX_CHECK(s, hipHostMalloc((void **)&f.v, sizeof(float) * cnt, hipHostMallocDefault));
+        f.stats = (int *)(f.x + r->x_words);
+        f.box = (double *)(f.stats + 8 * MDX_FRAME_WGS);
         MDX_CHECK(s, hipEventCreateWithFlags(&f.ev, hipEventDisableTiming));
-        MDX_CHECK(s, hipEventCreateWithFlags(&f.ev_staged, hipEventDisableTiming));
     }
-    // one staging buffer per slot so that consecutive captures do not wait for each other
-    MDX_CHECK(s, hipMalloc((void **)&r->d_stage, 2 * bytes * nslots));
-    MDX_CHECK(s, hipMalloc((void **)&r->d_box, sizeof(double) * 9 * nslots));
-    MDX_CHECK(s, hipMalloc((void **)&r->d_stats, sizeof(int) * 8 * MDX_FRAME_WGS * nslots));
     return MDX_OK;
+}
+
+static int flush_locked(mdx_system *s, FrameRing *r, hipStream_t st)
+{
+    const int n = s->n, nb = (n + 255) / 256;
+    for (int slot : r->pending) {
+        FrameSlot &f = r->slots[slot];
+        if (f.has_v) hipLaunchKernelGGL(k_unpack3, dim3(nb), dim3(256), 0, st, n, f.src_v, f.v, nullptr, nullptr);
+        if (f.quantized)
+            hipLaunchKernelGGL(k_frame_quantize, dim3(MDX_FRAME_WGS), dim3(256), 0, st, n, f.src_x, f.precision, (int *)f.x, f.stats,
+                               (const double *)s->d->boxd, f.box);
+        else
+            hipLaunchKernelGGL(k_unpack3, dim3(nb), dim3(256), 0, st, n, f.src_x, f.x, (const double *)s->d->boxd, f.box);
+        MDX_CHECK(s, hipGetLastError());
+        MDX_CHECK(s, hipEventRecord(f.ev, st));
+        f.enqueued = true;
+    }
+    r->pending.clear();
+    return MDX_OK;
+}
+// Launch the kernels of the frames captured since the last call on stream `st`, behind whatever it holds.
+int mdx_frames_flush(mdx_system *s, hipStream_t st)
+{
+    FrameRing *r = ring_of(s);
+    if (!r) return MDX_OK;
+    std::lock_guard<std::mutex> g(r->lock);
+    if (r->pending.empty()) return MDX_OK;
+    return flush_locked(s, r, st);
 }
 
 static int capture_frame(mdx_system *s, int slot, int want_v, bool quantize, float precision)
@@ -343,28 +378,13 @@ static int capture_frame(mdx_system *s, int slot, int want_v, bool quantize, flo
     FrameRing *r = ring_of(s);
     ARG_CHECK(s, r && slot >= 0 && slot < (int)r->slots.size(), "mdx_capture_frame: call mdx_frame_ring first / bad slot");
     FrameSlot &f = r->slots[slot];
-    const int n = s->n, nb = (n + 255) / 256;
-    const size_t cnt = 3 * (size_t)n;
-    float *dx = r->d_stage + 2 * cnt * slot, *dv = dx + cnt;
-    double *dbox = r->d_box + 9 * slot;
-    int *dstats = r->d_stats + 8 * MDX_FRAME_WGS * slot;
-    if (want_v) hipLaunchKernelGGL(k_unpack3, dim3(nb), dim3(256), 0, s->stream, n, s->v, dv, nullptr, nullptr);
-    if (quantize) {
-        hipExtLaunchKernelGGL(k_frame_quantize, dim3(MDX_FRAME_WGS), dim3(256), 0, s->stream, nullptr, f.ev_staged, 0, n, (const float4 *)s->x,
-                              precision, (int *)dx, dstats, (const double *)s->d->boxd, dbox);
-    } else {
-        hipExtLaunchKernelGGL(k_unpack3, dim3(nb), dim3(256), 0, s->stream, nullptr, f.ev_staged, 0, n, (const float4 *)s->x, dx,
-                              (const double *)s->d->boxd, dbox);
-    }
-    MDX_CHECK(s, hipGetLastError());
-    hipStream_t cs = s->st_bond;
-    MDX_CHECK(s, hipStreamWaitEvent(cs, f.ev_staged, 0));
-    MDX_CHECK(s, hipMemcpyAsync(f.x, dx, sizeof(float) * cnt, hipMemcpyDeviceToHost, cs));
-    if (want_v) MDX_CHECK(s, hipMemcpyAsync(f.v, dv, sizeof(float) * cnt, hipMemcpyDeviceToHost, cs));
-    MDX_CHECK(s, hipMemcpyAsync(f.box, dbox, sizeof(double) * 9, hipMemcpyDeviceToHost, cs));
-    if (quantize) MDX_CHECK(s, hipMemcpyAsync(f.stats, dstats, sizeof(int) * 8 * MDX_FRAME_WGS, hipMemcpyDeviceToHost, cs));
-    MDX_CHECK(s, hipEventRecord(f.ev, cs));
-    f.step = s->step; f.has_v = want_v ? 1 : 0; f.quantized = quantize ? 1 : 0;
+    std::lock_guard<std::mutex> g(r->lock);
+    ARG_CHECK(s, f.enqueued, "mdx_capture_frame: the slot's last capture has not been launched yet");
+    f.step = s->step; f.has_v = want_v ? 1 : 0; f.quantized = quantize ? 1 : 0; f.precision = precision;
+    f.src_x = (const float4 *)s->x; f.src_v = (const float4 *)s->v; f.enqueued = false;
+    r->pending.push_back(slot);
+    // (a decomposed run exchanges halo positions into the state between steps: no deferral there)
+    if (s->dd_on) return flush_locked(s, r, s->stream);
     return MDX_OK;
 }
 
@@ -374,6 +394,20 @@ extern "C" int mdx_capture_frame_xtc(mdx_system *s, int slot, int want_v, float 
 {
     ARG_CHECK(s, precision > 0.0f, "mdx_capture_frame_xtc: precision must be positive");
     return capture_frame(s, slot, want_v, true, precision);
+}
+
+// A waiting thread gives the stepping thread two milliseconds to reach the point of its step where it launches the capture
+// (it gets there within a step's enqueue time), then launches it itself on the main stream: a caller that captures and waits
+// without stepping.
+static int await_launched(mdx_system *s, FrameRing *r, FrameSlot &f)
+{
+    std::unique_lock<std::mutex> g(r->lock);
+    for (int spin = 0; !f.enqueued && spin < 40; spin++) {
+        g.unlock();
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+        g.lock();
+    }
+    return f.enqueued ? MDX_OK : flush_locked(s, r, s->stream);
 }
 
 // Blocks until the capture into `slot` has landed; the pointers stay valid until the slot is
@@ -386,6 +420,7 @@ extern "C" int mdx_frame_wait(mdx_system *s, int slot, const float **x, const fl
     ARG_CHECK(s, f.step >= 0, "mdx_frame_wait: nothing captured in this slot");
     ARG_CHECK(s, !f.quantized, "mdx_frame_wait: the slot holds xtc integers (mdx_frame_wait_xtc)");
     (void)hipSetDevice(s->device);
+    if (int rc = await_launched(s, r, f)) return rc;
     if (hipEventSynchronize(f.ev) != hipSuccess) { return MDX_ERR_HIP; }
     if (x) *x = f.x;
     if (v) *v = f.has_v ? f.v : nullptr;
@@ -402,6 +437,7 @@ extern "C" int mdx_frame_wait_xtc(mdx_system *s, int slot, const int **ix, const
     FrameSlot &f = r->slots[slot];
     ARG_CHECK(s, f.step >= 0 && f.quantized, "mdx_frame_wait_xtc: no xtc capture in this slot");
     (void)hipSetDevice(s->device);
+    if (int rc = await_launched(s, r, f)) return rc;
     if (hipEventSynchronize(f.ev) != hipSuccess) { return MDX_ERR_HIP; }
     if (ix) *ix = (const int *)f.x;
     if (v) *v = f.has_v ? f.v : nullptr;

@@ -425,14 +425,20 @@ __device__ __forceinline__ void d_fused_lincs(const FusedArgs &A, const int t, c
 // KE: the launch also leaves the half-step kinetic energy of the new velocities per T-group, as one set of partial sums per
 // workgroup (plain stores; the kernel that draws the thermostat's factors folds them): on the steps that end a coupling
 // period the kinetic energy then needs no pass of its own over the velocities behind the update.
-template <bool KE>
+// LARGE: the launch has a range of components of more than 4 constraints. Their path holds a 16 x 16 coupling matrix per
+// thread (255 registers and scratch memory), which as part of the one kernel would set the register allocation of every
+// workgroup, the waters' included: topologies constrained on bonds to hydrogens only have no such component (a heavy atom
+// carries at most four) and take the kernel without that path.
+template <bool KE, bool LARGE>
 __global__ __launch_bounds__(128) void k_update_fused(FusedArgs A)
 {
     MDX_STAMP(A.C.dw, 11);
     __shared__ float sh[5 * 7 * 128];       // LINCS ranges: 5 atoms x 7 values x 128 threads, or 17 x 7 x 32
     static_assert((MDX_LINCS_MAXK + 1) * 7 * MDX_FUSED_LARGE_THREADS <= 5 * 7 * 128, "LDS columns of the large components");
     const ConstrainArgs &C = A.C;
-    const int b = blockIdx.x;
+    // (workgroups are dispatched in index order: the ranges are taken back to front, so that the large constraint components,
+    // one thread walking through up to 17 atoms, start first and the waters fill in behind them)
+    const int b = gridDim.x - 1 - blockIdx.x;
     float keg[MDX_MAX_TC];
 #pragma unroll
     for (int k = 0; k < MDX_MAX_TC; k++) keg[k] = 0.0f;
@@ -485,7 +491,7 @@ __global__ __launch_bounds__(128) void k_update_fused(FusedArgs A)
             if (A.write_sorted) d_sorted_write(A, g, xo);
             if (KE) d_ke_add(keg, A.L.tcgrp[i], vi);
         }
-    } else {
+    } else if (LARGE) {
         if (threadIdx.x < MDX_FUSED_LARGE_THREADS)
             d_fused_lincs<MDX_LINCS_MAXK>(A, C.ncomp_small + (b - A.nbw3 - C.nb4 - A.nbfree) * MDX_FUSED_LARGE_THREADS + threadIdx.x, C.ncomp_small,
                                           C.ncomp - C.ncomp_small, sh, threadIdx.x, MDX_FUSED_LARGE_THREADS, KE ? keg : nullptr);
@@ -895,7 +901,8 @@ int mdx_launch_update_fused(mdx_system *s, bool do_tc, bool do_pr, bool write_so
         }
         A.ke_part = s->ke_part; s->ke_parts = nblocks;
     }
-    void (*kern)(FusedArgs) = with_ke ? k_update_fused<true> : k_update_fused<false>;
+    void (*kern)(FusedArgs) = nb16 > 0 ? (with_ke ? k_update_fused<true, true> : k_update_fused<false, true>)
+                                       : (with_ke ? k_update_fused<true, false> : k_update_fused<false, false>);
     if (nblocks > 0) {
         if (fork_signal) {
             hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(128), 0, s->stream, nullptr, s->ev_fork, 0, A);

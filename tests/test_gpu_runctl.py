@@ -189,3 +189,46 @@ def test_xtc_capture_rounds_on_the_gpu_like_the_host_encoder(small_complex, tmp_
     assert np.array_equal(files[0][0]["x"], files[1][0]["x"])                 # the same start state, rounded on either side
     for a, b in zip(files[0], files[1]):
         assert np.abs(a["x"] - b["x"]).max() < 2.1e-3                         # two runs: float atomics, then rounding to 1e-3
+
+
+def test_deferred_capture_edges(small_water):
+    """A capture is launched by the next step, beside its force kernels. The cases around that: a wait that no step
+    serves, a state replaced between the capture and the wait, a capture on a step that changes the cell (the frame
+    carries the cell the positions belong to), and a slot captured into twice with nothing in between."""
+    s = small_water
+    kw = dict(rc=1.0, nstcalcenergy=10, tc_groups=["System"], ref_t=[300.0], tau_t=[0.1], seed=3)
+    e = eng.Engine(s, **kw)
+    e.frame_ring(3)
+    e.step(4)
+    xa, va, ba = e.get_state()
+    # (1) capture, then wait without any step: the waiting side launches the capture itself
+    e.capture_frame(0, want_v=True)
+    st, x, v, b = e.frame_wait(0)
+    assert st == 4 and np.array_equal(x, xa) and np.array_equal(v, va)
+    # (2) the same slot twice with nothing in between is refused; after a synchronisation it is free again
+    e.capture_frame(1)
+    with pytest.raises(eng.MdxError):
+        e.capture_frame(1)
+    e.synchronize()
+    e.capture_frame(1)
+    # (3) the state replaced behind a capture: the frame still holds the state of the capture
+    e.capture_frame_xtc(2, 1000.0)
+    e.set_state(xa + 0.5, va, ba)
+    _, x1, _, _ = e.frame_wait(1)
+    _, ix, _, _, _ = e.frame_wait_xtc(2)
+    assert np.array_equal(x1, xa)
+    assert np.abs(ix / 1000.0 - xa).max() < 5.1e-4
+    e.close()
+    # (4) a frame ahead of a step that rescales the cell (C-rescale every 2 steps): cell and positions of the same moment
+    e = eng.Engine(s, pcoupl=1, tau_p=0.2, ref_p=1.0, compressibility=4.5e-4, nstpcouple=2, **kw)
+    e.frame_ring(2)
+    e.step(6)
+    xb, _, bb = e.get_state()
+    e.capture_frame(0)
+    e.step(4)
+    _, _, bc = e.get_state()
+    st, x, _, b = e.frame_wait(0)
+    # (get_state hands the cell out in single precision)
+    assert st == 6 and np.array_equal(x, xb) and np.abs(b - bb).max() < 3e-7
+    assert np.abs(np.asarray(bc) - np.asarray(bb)).max() > 3e-6          # the cell did move afterwards
+    e.close()
