@@ -222,9 +222,11 @@ extern "C" int mdx_minimize(mdx_system *s, long long nsteps, double emtol, doubl
 // update waits for, and write straight into the slot's pinned memory. On the main stream a capture costs nothing, and no
 // copy follows: a device-to-host copy is a kernel of the runtime's (30 us for 1.7 MB, on compute units, beside the energy
 // step's constraint kernel), and in front of it the staging kernel and its hand-over held the main stream for 12 us per frame.
-// The buffers a capture notes stay as they are through the next step: positions and velocities are double-buffered (the
-// step's update writes the other pair), the box changes only in the update. Anything else that rewrites the state
-// launches the pending captures first (mdx_frames_flush). A stream of their own for the frames would be the fourth of the
+// What a capture notes stays as it is until the next step's update: nothing ahead of the join touches positions, velocities
+// or the box, and the update (which writes the other position buffer, the velocities in place and, with pressure coupling,
+// the box) waits for the marker behind the capture's kernels. A waiting thread that launches them itself does so under the
+// ring's lock on the main stream, i.e. before the stepping thread can have enqueued that update. Anything else that
+// rewrites the state launches the pending captures first (mdx_frames_flush). A stream of their own for the frames would be the fourth of the
 // process: with four hardware queues per process it shares a queue with a compute stream and stalls it (measured twice:
 // +130 us per step in an early form of the step, 170 against 162 us per step in the present one).
 // A writer thread waits for the slot's event and encodes the frame.
