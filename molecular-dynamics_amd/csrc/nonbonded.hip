@@ -549,9 +549,12 @@ __device__ __forceinline__ void nb_energy_tab(const NbArgs &A)
     __syncthreads();
     nb_body<true, 2, NI, WGT, COUNT>(A, (const float2 *)tab4, ilj);
 }
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_ev(NbArgs A) { nb_energy_tab<4, false, false>(A); }
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_ev_count(NbArgs A) { nb_energy_tab<4, false, true>(A); }
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_ev_dd(NbArgs A) { nb_energy_tab<4, true, true>(A); }
+// (waves_per_eu(3, 4), not (3, 3): an upper bound of three waves makes the compiler pad the register allocation past 128 so that a
+// fourth wave cannot fit, 136 per wave, and the 104 registers that leaves a SIMD do not hold the two waves per SIMD of a PME
+// plane workgroup: beside the energy kernel the whole PME chain then waited for nonbonded workgroups to retire)
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_nonbonded_ev(NbArgs A) { nb_energy_tab<4, false, false>(A); }
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_nonbonded_ev_count(NbArgs A) { nb_energy_tab<4, false, true>(A); }
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_nonbonded_ev_dd(NbArgs A) { nb_energy_tab<4, true, true>(A); }
 // Analytic kernels (rational Ewald correction, exp + erfc polynomial in the energy kernel): what a handle without Ewald
 // tables runs, and the cross-check of the tabulated kernels (mdx_debug_set key 2 bit 0x400000).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f_analytic(NbArgs A) { nb_body<false, 0>(A); }
