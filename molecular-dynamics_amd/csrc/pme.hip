@@ -457,7 +457,7 @@ __device__ __forceinline__ void dft_lines_fast(float2 *a, float2 *b, const float
 
 // MODE 0: x forward (real lines -> half-complex), 4: x inverse; 1 / 3: y forward / inverse; 2: z forward, solve, z inverse
 template <int MODE, bool ENERGY>
-__global__ __launch_bounds__(256) void k_pme_fft(FftArgs A)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_pme_fft(FftArgs A)
 {
     MDX_STAMP(A.d, 4 + MODE);
     extern __shared__ float2 fsm[];
