@@ -756,8 +756,12 @@ int mdx_join(mdx_system *s)
 {
     if (!s->pme_signalled) MDX_CHECK(s, hipEventRecord(s->ev_pme, s->st_pme));
     s->pme_signalled = false;
-    MDX_CHECK(s, hipEventRecord(s->ev_bond, s->st_bond));
-    MDX_CHECK(s, hipStreamWaitEvent(s->stream, s->ev_bond, 0));
+    // (a step whose bonded work rode in the spreading launch and that put nothing else on the bonded stream has one wait)
+    if (s->bond_busy) {
+        MDX_CHECK(s, hipEventRecord(s->ev_bond, s->st_bond));
+        MDX_CHECK(s, hipStreamWaitEvent(s->stream, s->ev_bond, 0));
+    }
+    s->bond_busy = true;
     MDX_CHECK(s, hipStreamWaitEvent(s->stream, s->ev_pme, 0));
     return MDX_OK;
 }
@@ -947,17 +951,22 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
         prepared = false;
         // Thermostat factors of the coupling period that the previous step ended: drawn on the bonded stream, which has just
         // been released behind that step's update; the join orders it ahead of this step's update, the first to use them.
-        if (s->tc_fold_pending) { s->tc_fold_pending = false; if ((rc = mdx_launch_tcouple_fold(s, s->st_bond, s->tc_fold_step))) return rc; }
+        // On a step without energies, pull or domain decomposition the bonded terms ride in the spreading launch; the bonded
+        // stream then carries this step's work only when the thermostat's factors or a trajectory frame are due.
+        const bool merge_bonded = phase == 0 && !need_vir && s->have_pme && !s->one_stream && !s->dd_on && !s->pull_on && !(s->dbg & 0x4000000);
+        s->bond_busy = !merge_bonded || s->bond_carry;       // (bond_carry: the previous step left work there that this step's update needs)
+        s->bond_carry = false;
+        if (s->tc_fold_pending) { s->tc_fold_pending = false; s->bond_busy = true; if ((rc = mdx_launch_tcouple_fold(s, s->st_bond, s->tc_fold_step))) return rc; }
         // the nonbonded kernel is the critical path: enqueue it first, the side streams fill in
         if ((rc = mdx_launch_nonbonded(s, need_vir, MDX_F_NONBONDED | (s->have_pme ? MDX_F_EXCL : 0)))) return rc;
         if (phase == 0) {
-            if ((rc = mdx_launch_pme(s, need_vir, false))) return rc;
+            if ((rc = mdx_launch_pme(s, need_vir, false, 0, merge_bonded ? (MDX_F_BONDED | MDX_F_POSRES) : 0u))) return rc;
         } else if (s->have_pme) {
             if (slabs) { if ((rc = mdx_launch_pme(s, false, false, 1))) return rc; }
             else if ((rc = mdx_launch_pme_spread(s, s->st_pme))) return rc;
             MDX_CHECK(s, hipEventRecord(s->ev_spread, s->st_pme));
         }
-        if ((rc = mdx_launch_bonded(s, need_vir, MDX_F_BONDED | MDX_F_POSRES))) return rc;
+        if (!merge_bonded) if ((rc = mdx_launch_bonded(s, need_vir, MDX_F_BONDED | MDX_F_POSRES))) return rc;
         // kinetic energy of the half step behind: reads only the velocities, which the update (behind the join) changes,
         // so it runs on the bonded stream beside the nonbonded kernel instead of ahead of it on the main stream
         if (need_vir) if ((rc = mdx_launch_ke(s, true, true, s->st_bond))) return rc;
@@ -973,7 +982,8 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
     if (phase == 2) if ((rc = slabs ? mdx_launch_pme(s, false, true, 3) : mdx_launch_pme(s, need_vir && s->dd_mesh_energy, true))) return rc;
     // trajectory frames captured ahead of this step: written to their pinned slots on the bonded stream, beside the nonbonded
     // kernel and ahead of the marker the update waits for (the update changes the box, and the next one the captured buffers)
-    if (s->frame_ring) if ((rc = mdx_frames_flush(s, s->st_bond))) return rc;
+    if (s->frame_ring) { bool any = false; if ((rc = mdx_frames_flush(s, s->st_bond, &any))) return rc; if (any) s->bond_busy = true; }
+    if (phase == 2) s->bond_busy = true;
     if ((rc = mdx_join(s))) return rc;
     if (do_prune) {
         // Beside this step's nonbonded kernel (which still reads the list of the last prune, or on a search step the outer
@@ -1024,7 +1034,7 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
         // update, so they are drawn beside the next step: on the bonded stream, at once when this step's update has
         // released that stream already, otherwise when the next step releases it.
         s->tc_fold_pending = true; s->tc_fold_step = step;
-        if (forked_early) { s->tc_fold_pending = false; if ((rc = mdx_launch_tcouple_fold(s, s->st_bond, step))) return rc; }
+        if (forked_early) { s->tc_fold_pending = false; s->bond_carry = true; if ((rc = mdx_launch_tcouple_fold(s, s->st_bond, step))) return rc; }
     } else if (s->ntc > 0 && ((step + 1) % s->nsttcouple == 0) && !need_vir && !s->dd_on) {
         // the thermostat's own accumulator, which the kernel that draws the factor leaves zeroed: no clearing launch
         if ((rc = mdx_launch_ke(s, false, false, nullptr, true))) return rc;

@@ -126,6 +126,8 @@ struct mdx_system {
     int nb_dyn_split = 0;              // ... in 2^nb_dyn_split parts per unit (mdx_debug_set key 4)
     int pme_part = 0;                  // stage timing: 1 only the spreading, 2 only the gather of the PME chain
     long long *nb_wave_t = nullptr;    // diagnostic per-wave clock buffer (mdx_debug_wave_times)
+    bool bond_carry = false;           // ... left there by the previous step (thermostat factors drawn behind its update)
+    bool bond_busy = true;             // the bonded stream holds work of this step that the update has to wait for
     bool one_stream = false;           // st_pme and st_bond are the main stream (no cross-stream waits at all)
     hipStream_t own_streams[3] = { nullptr, nullptr, nullptr };   // the three streams created for the handle (destroyed with it)
     hipStream_t stream = nullptr;      // main stream: search, nonbonded, update
@@ -294,8 +296,10 @@ int mdx_launch_prepare(mdx_system *s, bool fork = false);
 int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms);
 // stage 0: the whole chain; 1: spreading (unless done) and x forward; 2: y/z transforms and influence function on this
 // domain's planes; 3: x inverse and gather
-int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done = false, int stage = 0);
-int mdx_launch_pme_spread(mdx_system *s, hipStream_t st);
+int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done = false, int stage = 0, unsigned bonded_flags = 0);
+int mdx_launch_pme_spread(mdx_system *s, hipStream_t st, unsigned bonded_flags = 0);
+struct BondedArgs;
+void mdx_bonded_args(mdx_system *s, unsigned flags, BondedArgs &A);
 int mdx_launch_bonded(mdx_system *s, bool energy, unsigned flags);
 int mdx_launch_pull(mdx_system *s, bool log_now, bool energy);
 int mdx_launch_update(mdx_system *s, bool do_tc, bool do_pr, bool virial);
@@ -304,7 +308,7 @@ int mdx_fused_plan(mdx_system *s);
 int mdx_launch_update_fused(mdx_system *s, bool do_tc, bool do_pr, bool write_sorted, bool fork_signal, bool with_ke = false);
 int mdx_launch_tcouple_fold(mdx_system *s, hipStream_t st, long long step);
 void mdx_frames_free(mdx_system *s);
-int mdx_frames_flush(mdx_system *s, hipStream_t st);      // launch the kernels of captured trajectory frames on `st` (behind what it holds)
+int mdx_frames_flush(mdx_system *s, hipStream_t st, bool *any = nullptr);      // launch the kernels of captured trajectory frames on `st` (behind what it holds)
 int mdx_launch_ke(mdx_system *s, bool old_slot, bool tensor, hipStream_t st = nullptr, bool tc_slot = false);
 int mdx_launch_comm_phase(mdx_system *s, int phase);
 int mdx_launch_clear(mdx_system *s, bool energies, bool ekin_new, bool ekin_old);

@@ -4,6 +4,7 @@
 // Grid layout: (nx, ny, nz) with z fastest; fractional coordinates s = x . inv(box) so the
 // triclinic dodecahedron needs no special casing; reciprocal vectors m = inv(box) . m'.
 #include "mdx_internal.h"
+#include "bonded_body.h"
 #include <hip/hip_ext.h>
 #include <algorithm>
 #include <cstdlib>
@@ -83,10 +84,8 @@ struct SpreadSlabArgs {
 };
 #define MDX_SPREAD_MAXSC 256            // candidate super-clusters of one workgroup (qx qy columns of at most 32 each)
 
-__global__ __launch_bounds__(256) void k_pme_spread_slab(SpreadSlabArgs A, const DevState *__restrict__ d)
+__device__ __forceinline__ void spread_slab_block(const SpreadSlabArgs &A, const DevState *__restrict__ d, const int block_y, float *tile)
 {
-    MDX_STAMP_ALL(d, 3);
-    extern __shared__ float tile[];
     int *ox = (int *)(tile + A.SP * A.T1 * A.T0);
     int *oy = ox + A.SP, *oxw = oy + A.SP, *oyw = oxw + A.SP;         // window origins per plane: as computed, and wrapped into the grid
     __shared__ int s_list[MDX_SPREAD_MAXSC];
@@ -94,7 +93,7 @@ __global__ __launch_bounds__(256) void k_pme_spread_slab(SpreadSlabArgs A, const
     const int nqx = (A.ncx + A.qx - 1) / A.qx;
     const int cx0 = (blockIdx.x % nqx) * A.qx, cy0 = (blockIdx.x / nqx) * A.qy;
     const int ncolx = min(A.qx, A.ncx - cx0), ncoly = min(A.qy, A.ncy - cy0);
-    const int tlo = A.tlo0 + blockIdx.y * A.SP;
+    const int tlo = A.tlo0 + block_y * A.SP;
     const DevBox &bx = d->box;
     const float wx = bx.h[0] / A.ncx, wy = bx.h[4] / A.ncy;
     const float x_lo = cx0 * wx - A.delta;
@@ -201,6 +200,28 @@ __global__ __launch_bounds__(256) void k_pme_spread_slab(SpreadSlabArgs A, const
             gz++; gz -= gz >= A.K2 ? A.K2 : 0;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_pme_spread_slab(SpreadSlabArgs A, const DevState *__restrict__ d)
+{
+    MDX_STAMP_ALL(d, 3);
+    extern __shared__ float tile[];
+    spread_slab_block(A, d, blockIdx.y, tile);
+}
+// The spreading with the step's bonded work in the same launch: the first `brows` rows of the grid (dispatched first) are
+// workgroups of the bonded launch, which keep their force window in the dynamic LDS the spreading windows use. On a step
+// without energies the bonded stream then carries nothing, and the update waits for one other stream instead of two
+// (a wait for an event of another stream costs the main stream 2-3 us even when the event has long fired).
+__global__ __launch_bounds__(256) void k_pme_spread_slab_bonded(SpreadSlabArgs A, const DevState *__restrict__ d, BondedArgs B, int brows)
+{
+    extern __shared__ float tile[];
+    if ((int)blockIdx.y < brows) {
+        const int b = blockIdx.y * gridDim.x + blockIdx.x;
+        if (b < B.nblocks) bonded_block<false>(B, b, tile, (int *)(tile + 3 * MDX_BWIN));
+        return;
+    }
+    MDX_STAMP_ALL(d, 3);
+    spread_slab_block(A, d, (int)blockIdx.y - brows, tile);
 }
 
 // Multiply the transformed grid by the Ewald influence function; optionally accumulate the
@@ -863,7 +884,8 @@ void mdx_pme_free(mdx_system *s)
 }
 
 // Zero the charge grid (unless the last transform's x pass left it zeroed) and spread onto it, on stream `st`.
-int mdx_launch_pme_spread(mdx_system *s, hipStream_t st)
+// bonded_flags (MDX_F_BONDED | MDX_F_POSRES, or 0): the bonded terms of a step without energies ride in the same launch.
+int mdx_launch_pme_spread(mdx_system *s, hipStream_t st, unsigned bonded_flags)
 {
     if (!s->have_pme) return MDX_OK;
     const int K0 = s->K[0], K1 = s->K[1], K2 = s->K[2];
@@ -891,9 +913,15 @@ int mdx_launch_pme_spread(mdx_system *s, hipStream_t st)
     B.tlo0 = -4;
     const int nslab = (K2 + 12 + B.SP - 1) / B.SP;
     B.delta = (float)delta; B.grid = s->grid; B.v_home = s->dd_on ? s->v : nullptr;
-    const size_t ldss = (size_t)B.SP * B.T0 * B.T1 * 4 + (size_t)B.SP * 16;
+    size_t ldss = (size_t)B.SP * B.T0 * B.T1 * 4 + (size_t)B.SP * 16;
     const int nq = ((s->ncx + B.qx - 1) / B.qx) * ((s->ncy + B.qy - 1) / B.qy);
-    hipLaunchKernelGGL(k_pme_spread_slab, dim3(nq, nslab), dim3(256), ldss, st, B, (const DevState *)s->d);
+    BondedArgs G; G.nblocks = 0;
+    if (bonded_flags) mdx_bonded_args(s, bonded_flags, G);
+    if (G.nblocks > 0) {
+        const int brows = (G.nblocks + nq - 1) / nq;
+        ldss = std::max(ldss, sizeof(float) * 3 * MDX_BWIN + sizeof(int));
+        hipLaunchKernelGGL(k_pme_spread_slab_bonded, dim3(nq, nslab + brows), dim3(256), ldss, st, B, (const DevState *)s->d, G, brows);
+    } else hipLaunchKernelGGL(k_pme_spread_slab, dim3(nq, nslab), dim3(256), ldss, st, B, (const DevState *)s->d);
     MDX_CHECK(s, hipGetLastError());
     return MDX_OK;
 }
@@ -903,7 +931,7 @@ int mdx_launch_pme_spread(mdx_system *s, hipStream_t st)
 // restricts the chain to the spreading (1) or the gather (2). `stage` cuts the chain where domains that share the
 // transform exchange the half-complex grid: 1 ends behind the x forward pass, 2 is the fused y/z kernel on this domain's
 // planes, 3 the x inverse pass and the gather (0: everything).
-int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done, int stage)
+int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done, int stage, unsigned bonded_flags)
 {
     if (!s->have_pme) return MDX_OK;
     const int K0 = s->K[0], K1 = s->K[1], K2 = s->K[2];
@@ -916,7 +944,7 @@ int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done, int stage)
         MDX_CHECK(s, hipGetLastError());
         return MDX_OK;
     }
-    if (stage <= 1 && !spread_done) { int rc = mdx_launch_pme_spread(s, s->st_pme); if (rc) return rc; }
+    if (stage <= 1 && !spread_done) { int rc = mdx_launch_pme_spread(s, s->st_pme, energy ? 0u : bonded_flags); if (rc) return rc; }
     if (s->pme_part == 1) return MDX_OK;
     const float *potential = s->grid;       // the library path transforms in place
     if (s->own_fft && (stage != 0 || !(s->dbg & 512))) {

@@ -365,12 +365,13 @@ static int flush_locked(mdx_system *s, FrameRing *r, hipStream_t st)
     return MDX_OK;
 }
 // Launch the kernels of the frames captured since the last call on stream `st`, behind whatever it holds.
-int mdx_frames_flush(mdx_system *s, hipStream_t st)
+int mdx_frames_flush(mdx_system *s, hipStream_t st, bool *any)
 {
     FrameRing *r = ring_of(s);
     if (!r) return MDX_OK;
     std::lock_guard<std::mutex> g(r->lock);
     if (r->pending.empty()) return MDX_OK;
+    if (any) *any = true;
     return flush_locked(s, r, st);
 }
 

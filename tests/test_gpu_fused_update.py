@@ -59,6 +59,34 @@ def test_fused_and_separate_kernels_agree(small_complex, pcoupl):
     assert np.allclose(fa[:, 2 + pot], fb[:, 2 + pot], rtol=2e-6)
 
 
+def test_bonded_terms_in_the_spreading_launch_agree_with_their_own_launch(small_complex):
+    """On steps without energies the bonded terms ride in the charge-spreading launch and the update waits for the PME
+    stream only (thermostat steps and frames put work on the bonded stream again). The same 23 steps with the bonded
+    launch kept separate (mdx_debug_set key 2, bit 0x4000000), up to the order of the float32 force sums; a trajectory
+    frame captured on the way arrives either way."""
+    s = small_complex
+    out = []
+    for separate in (0, 1):
+        e = eng.Engine(s, rc=1.0, dt=0.002, nstlist=10, nstcalcenergy=10, tc_groups=["Protein", "Non-Protein"], ref_t=[300.0] * 2,
+                       tau_t=[0.1] * 2, nsttcouple=5, seed=7)
+        if separate:
+            e.debug_set(2, 0x4000000)
+        e.frame_ring(2)
+        e.set_state(s.x, s.v, s.box); e.set_step(0)
+        e.step(12)
+        e.capture_frame(0)
+        for n in (1, 7, 3):
+            e.step(n)
+        x, v, _ = e.get_state()
+        _, xf, _, _ = e.frame_wait(0)
+        out.append((x.astype(np.float64), v.astype(np.float64), xf.astype(np.float64)))
+        e.close()
+    (xa, va, fa), (xb, vb, fb) = out
+    assert np.sqrt(((xa - xb) ** 2).sum(1).mean()) < 5e-6
+    assert np.sqrt(((va - vb) ** 2).sum(1).mean()) < 5e-3 * np.sqrt((vb ** 2).sum(1).mean())
+    assert np.sqrt(((fa - fb) ** 2).sum(1).mean()) < 5e-6
+
+
 def test_fused_update_water_keeps_geometry_over_a_search(small_water):
     s = small_water
     e = eng.Engine(s, rc=1.0, nstcalcenergy=0, nstlist=10, dt=0.002)
