@@ -939,7 +939,8 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
             if ((rc = mdx_launch_tcouple(s))) return rc;
         }
         s->first_step = false;
-        if (need_vir) if ((rc = mdx_launch_clear(s, true, true, true))) return rc;
+        // (accumulators of a step with energies: cleared by the prepare kernel where one is launched for this step)
+        if (need_vir && prepared) if ((rc = mdx_launch_clear(s, true, true, true))) return rc;
         // the leap-frog kernel leaves f cleared; only a force evaluation outside the step loop dirties it
         if (s->f_dirty) { MDX_CHECK(s, hipMemsetAsync(s->f, 0, sizeof(float) * 3 * s->n, s->stream)); s->f_dirty = false; }
         if (do_search) if ((rc = mdx_search(s))) return rc;
@@ -947,7 +948,7 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
         // an event recorded by a separate marker costs the main stream several microseconds)
         // (a fused update of the previous step in this call has already left the sorted coordinates of this one)
         if (prepared) { if (!forked_early) if ((rc = mdx_fork(s))) return rc; }
-        else if ((rc = mdx_launch_prepare(s, !forked_early))) return rc;
+        else if ((rc = mdx_launch_prepare(s, !forked_early, need_vir ? 7 : 0))) return rc;
         prepared = false;
         // Thermostat factors of the coupling period that the previous step ended: drawn on the bonded stream, which has just
         // been released behind that step's update; the join orders it ahead of this step's update, the first to use them.

@@ -275,6 +275,25 @@ struct mdx_system {
     void *frame_ring = nullptr;   // pinned trajectory-frame slots (runctl.hip)
 };
 
+// Zero the accumulators that a step's kernels add into; threads t = 0 .. 63 of one workgroup.
+__device__ __forceinline__ void mdx_clear_accumulators(DevState *dw, const int t, const int energies, const int ekin_new, const int ekin_old)
+{
+    if (energies) {
+        if (t < MDX_E_N) dw->ener[t] = 0.0;
+        if (t < 9) { dw->vir[t] = 0.0; dw->ekin_tensor[t] = 0.0; }
+        if (t == 0) { dw->npairs_rc = 0; dw->npairs_lj = 0; }
+        if (t < MDX_NREP) {     // one replica row per thread
+            for (int k = 0; k < MDX_E_N; k++) dw->ener_rep[t][k] = 0.0;
+            for (int k = 0; k < 9; k++) { dw->vir_rep[t][k] = 0.0; dw->ekt_rep[t][k] = 0.0; }
+            dw->npairs_rep[t][0] = 0; dw->npairs_rep[t][1] = 0;
+        }
+    }
+    if (t < MDX_MAX_TC) {
+        if (ekin_new) dw->ekinh[t] = 0.0;
+        if (ekin_old) dw->ekinh_old[t] = 0.0;
+    }
+}
+
 #define MDX_CHECK(sys, call)                                                                         \
     do {                                                                                             \
         hipError_t e_ = (call);                                                                      \
@@ -292,7 +311,7 @@ int mdx_launch_prune(mdx_system *s, hipStream_t st);
 int mdx_wait_prune(mdx_system *s);
 int mdx_fork(mdx_system *s);
 int mdx_join(mdx_system *s);
-int mdx_launch_prepare(mdx_system *s, bool fork = false);
+int mdx_launch_prepare(mdx_system *s, bool fork = false, int clear_mask = 0);      // clear_mask: 1 energies, 2 new, 4 old half-step kinetic energy
 int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms);
 // stage 0: the whole chain; 1: spreading (unless done) and x forward; 2: y/z transforms and influence function on this
 // domain's planes; 3: x inverse and gather

@@ -677,10 +677,12 @@ __global__ __launch_bounds__(1024) void k_sort_work(DevState *__restrict__ d, co
 __global__ void k_prepare(int npad, DevState *__restrict__ d, const float4 *__restrict__ x,
                           const int *__restrict__ perm, const int *__restrict__ perm_src,
                           const int *__restrict__ shift_s, float4 *__restrict__ xq_s, float *__restrict__ f_s,
-                          int nshift, const int3 *__restrict__ shift_ijk, float4 *__restrict__ shiftvec)
+                          int nshift, const int3 *__restrict__ shift_ijk, float4 *__restrict__ shiftvec, int clear_mask)
 {
     MDX_STAMP(d, 0);
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    // (a step that accumulates energies: their accumulators are cleared here instead of by a launch of their own)
+    if (clear_mask && g < 64) mdx_clear_accumulators(d, g, clear_mask & 1, clear_mask & 2, clear_mask & 4);
     const float *h = d->box.h;
     if (g < 8) d->nb_head[g * 32] = 0;       // unit queues of the nonbonded kernel
     if (g < nshift) {
@@ -703,21 +705,21 @@ __global__ void k_prepare(int npad, DevState *__restrict__ d, const float4 *__re
 
 // With `fork` the kernel's own completion signal is the fork event of the side streams (an event
 // recorded by a separate marker costs the main stream several microseconds between two kernels).
-int mdx_launch_prepare(mdx_system *s, bool fork)
+int mdx_launch_prepare(mdx_system *s, bool fork, int clear_mask)
 {
     { const int rc = mdx_wait_prune(s); if (rc) return rc; }
     const int nb = (s->npad + 255) / 256;
     if (fork) {
         hipExtLaunchKernelGGL(k_prepare, dim3(nb), dim3(256), 0, s->stream, nullptr, s->ev_fork, 0, s->npad, s->d,
                               (const float4 *)s->x, (const int *)s->perm, (const int *)s->perm_src, (const int *)s->shift_s,
-                              s->xq_s, s->f_s, s->nshift, (const int3 *)s->shift_ijk, s->shiftvec);
+                              s->xq_s, s->f_s, s->nshift, (const int3 *)s->shift_ijk, s->shiftvec, clear_mask);
         MDX_CHECK(s, hipGetLastError());
         MDX_CHECK(s, hipStreamWaitEvent(s->st_pme, s->ev_fork, 0));
         MDX_CHECK(s, hipStreamWaitEvent(s->st_bond, s->ev_fork, 0));
         return MDX_OK;
     }
     hipLaunchKernelGGL(k_prepare, dim3(nb), dim3(256), 0, s->stream, s->npad, s->d, s->x, s->perm, s->perm_src,
-                       s->shift_s, s->xq_s, s->f_s, s->nshift, s->shift_ijk, s->shiftvec);
+                       s->shift_s, s->xq_s, s->f_s, s->nshift, s->shift_ijk, s->shiftvec, clear_mask);
     MDX_CHECK(s, hipGetLastError());
     return MDX_OK;
 }

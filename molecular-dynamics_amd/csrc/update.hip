@@ -956,24 +956,11 @@ int mdx_launch_ke(mdx_system *s, bool old_slot, bool tensor, hipStream_t st, boo
     return MDX_OK;
 }
 
-// Zero the accumulators that the coming step's kernels add into.
+// Zero the accumulators that the coming step's kernels add into (the body, mdx_clear_accumulators, is shared with the
+// prepare kernel, which clears them itself when it is launched for such a step anyway).
 __global__ void k_clear(DevState *dw, int energies, int ekin_new, int ekin_old)
 {
-    const int t = threadIdx.x;
-    if (energies) {
-        if (t < MDX_E_N) dw->ener[t] = 0.0;
-        if (t < 9) { dw->vir[t] = 0.0; dw->ekin_tensor[t] = 0.0; }
-        if (t == 0) { dw->npairs_rc = 0; dw->npairs_lj = 0; }
-        if (t < MDX_NREP) {     // one replica row per thread
-            for (int k = 0; k < MDX_E_N; k++) dw->ener_rep[t][k] = 0.0;
-            for (int k = 0; k < 9; k++) { dw->vir_rep[t][k] = 0.0; dw->ekt_rep[t][k] = 0.0; }
-            dw->npairs_rep[t][0] = 0; dw->npairs_rep[t][1] = 0;
-        }
-    }
-    if (t < MDX_MAX_TC) {
-        if (ekin_new) dw->ekinh[t] = 0.0;
-        if (ekin_old) dw->ekinh_old[t] = 0.0;
-    }
+    mdx_clear_accumulators(dw, threadIdx.x, energies, ekin_new, ekin_old);
 }
 
 int mdx_launch_clear(mdx_system *s, bool energies, bool ekin_new, bool ekin_old)
