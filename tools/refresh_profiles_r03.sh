@@ -18,6 +18,9 @@ bash tools/nb_pmc.sh > $O/nb_pmc.log 2>&1 || { tail -5 $O/nb_pmc.log; exit 1; }
 cp gpurun_out/nb_pmc_traffic.json $O/
 bash tools/nb_sq3.sh > $O/nb_sq_counters.txt 2>&1 || exit 1
 KERN="k_nonbonded_ev(" MDX_NB_ENERGY=1 bash tools/nb_sq3.sh > $O/nb_energy_sq_counters.txt 2>&1 || exit 1
+timeout -k 10 300 python tools/plain_step_period.py > $O/plain_step_period.txt 2>/dev/null || exit 1
+timeout -k 10 300 python tools/frame_cost.py 2>/dev/null | tail -2 > $O/frame_cost.txt || exit 1
+bash tools/frame_trace.sh > /dev/null 2>&1 || exit 1
 python - <<'PY'
 import json
 for f in ("bench_default", "bench_20_steps_driver_invocation"):
