@@ -5,8 +5,7 @@ Workload (N=1 and every N as independent replicas, weak scaling): the synthetic 
 (alkane-bundle "protein" + 44-atom ligand + Na+ + TIP3P, rhombic dodecahedron d = 12.5 nm,
 ~1.4e5 atoms) run with the settings of /root/reference/mdp/production.mdp (dt 2 fs, rc 1.0 nm,
 PME order 4 / 0.16 nm, h-bond constraints, V-rescale on Protein / Non-Protein, energies every
-10 steps, DispCorr EnerPres, Parrinello-Rahman barostat; --pcoupl c-rescale selects the barostat that BASELINE.json's
-config names instead).
+10 steps, DispCorr EnerPres, Parrinello-Rahman barostat; --pcoupl c-rescale selects stochastic cell rescaling instead).
 A "step" is one MD step. Metric: ns/day = dt * steps * 86400 / wall / 1000 summed over replicas.
 """
 import argparse

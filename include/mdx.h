@@ -309,8 +309,8 @@ int mdx_dd_scalars(mdx_system *sys, void **ekinh_dev, void **com_dev);
 int mdx_dd_tcouple(mdx_system *sys, int before_first_step);
 int mdx_dd_kinetic(mdx_system *sys);
 int mdx_dd_com(mdx_system *sys, int phase);
-/* Pressure coupling of a decomposed run (C-rescale, `pcoupl`/`tau_p`/`ref_p`/`compressibility` of
- * /root/reference/mdp/production.mdp:36-40 with the barostat BASELINE.json names): a coupling step leaves the domain's
+/* Pressure coupling of a decomposed run (`pcoupl`/`tau_p`/`ref_p`/`compressibility` of
+ * /root/reference/mdp/production.mdp:36-40, Parrinello-Rahman there, or C-rescale): a coupling step leaves the domain's
  * share of the pressure tensor at `pres_dev` (9 doubles); the caller sums it over the domains and calls mdx_dd_pcouple,
  * which scales box, atoms and velocities by the factor every domain draws alike and returns the new box. */
 int mdx_dd_pressure(mdx_system *sys, void **pres_dev);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything the committed third-round profiles are made from (GPU box, repository root): the GPU tests, the smoke
+# Everything the committed profiles under profiles/r03 are made from (GPU box, repository root): the GPU tests, the smoke
 # entry, the default bench line (with its command-line leg), the driver's 20-step invocation, the kernel trace statistics
 # of the bench command, the in-kernel step timeline on the dual pair list, and the counter passes of the nonbonded
 # kernel. Each GPU step has its own time limit; the script stops at the first failure.
