@@ -651,8 +651,13 @@ def mdrun(argv, out=sys.stdout, err=sys.stderr) -> int:
             if writer is not None and (wx or tx or tv):
                 writer.capture(wx, tx, tv)
 
-        def drain():
-            for fr in eng.pop_energy_frames():
+        def fetch():
+            """Energy frames and pull records recorded since the last call (synchronises with the device)."""
+            return eng.pop_energy_frames(), (eng.pop_pull_records() if pull else [])
+
+        def write(fetched):
+            frames, records = fetched
+            for fr in frames:
                 s = int(fr[0])
                 if appending and s == step0:
                     continue
@@ -663,7 +668,7 @@ def mdrun(argv, out=sys.stdout, err=sys.stderr) -> int:
                 if due(nst_log, s):
                     log.energies(s, tinit + s * dt, terms)
             if pull:
-                for (t, val, force, _work) in eng.pop_pull_records():
+                for (t, val, force, _work) in records:
                     s = int(round(t / dt))
                     if px is not None and due(nst_px, s):
                         px.row(tinit + t, val)
@@ -677,9 +682,11 @@ def mdrun(argv, out=sys.stdout, err=sys.stderr) -> int:
         cadences = [c for c in (nst_xtc if xtc is not None else 0, nst_x, nst_v) if c > 0]
         step = step0
         chunk_cap = 250
-        last_print = last_cpt = time.time()
+        last_print = last_cpt = last_fetch = time.time()
         t_loop0 = time.time()
         steps_run = 0
+        fetched = None
+        prof = {"capture": 0.0, "step": 0.0, "write": 0.0, "fetch": 0.0}     # where this thread's time goes (MDX_RUNNER_TIMES=1 prints it)
         out.write(f"starting mdrun '{sysm.title}'\n{nsteps} steps, {nsteps * dt:8.1f} ps"
                   + (f" (continuing from step {step0}, {step0 * dt:8.1f} ps).\n" if step0 else ".\n"))
         out.flush()
@@ -691,19 +698,34 @@ def mdrun(argv, out=sys.stdout, err=sys.stderr) -> int:
                 if writer is not None:
                     writer.wait_idle()
                 t_loop0 = time.time(); steps_run = 0; reset_pending = False
+                prof = dict.fromkeys(prof, 0.0)
                 log.note(f"\nStep {step}: resetting all time and cycle counters")
+            tp0 = time.perf_counter()
             maybe_capture(step)
+            tp1 = time.perf_counter()
             nxt = min(nsteps, step + chunk_cap)
             for c in cadences:
                 nxt = min(nxt, (step // c + 1) * c)
             eng.step(nxt - step)
+            tp2 = time.perf_counter()
+            prof["capture"] += tp1 - tp0; prof["step"] += tp2 - tp1
             steps_run += nxt - step
             step = nxt
+            if fetched is not None:
+                # what the last fetch brought is written while the device works on the steps enqueued since (a second of
+                # the production cadence is 650 energy frames for .edr and .log: 20 ms of this thread)
+                write(fetched); fetched = None
+                prof["write"] += time.perf_counter() - tp2
             now = time.time()
-            if now - last_print >= 1.0 or step >= nsteps:
-                drain()          # synchronises: keeps the host at most one chunk ahead of the device
+            if now - last_fetch >= 0.2 and step < nsteps:
+                tp3 = time.perf_counter()
+                # (synchronises: keeps the host at most a fifth of a second of steps ahead of the device, and what is left to
+                # write behind the last step short)
+                fetched = fetch(); last_fetch = now
+                prof["fetch"] += time.perf_counter() - tp3
                 if writer is not None and writer.error is not None:
                     raise writer.error
+            if now - last_print >= 1.0 or step >= nsteps:
                 if a.v or True:
                     rate = steps_run / max(now - t_loop0, 1e-9)
                     remain = (nsteps - step) / max(rate, 1e-9)
@@ -715,10 +737,14 @@ def mdrun(argv, out=sys.stdout, err=sys.stderr) -> int:
                     tprio.save_checkpoint(f_cpt, step, tinit + step * dt, x_, v_, b_, extra=dict(run_state=[float(r) for r in eng.get_run_state()]))
                     last_cpt = now
         # the frame of the final step
+        t_tail = time.perf_counter()
         if not stop["flag"]:
             maybe_capture(step)
         eng.synchronize()
-        drain()
+        prof["tail: last steps on the device"] = time.perf_counter() - t_tail
+        if fetched is not None:
+            write(fetched)
+        write(fetch())
         if not stop["flag"] and (due(nst_e, step) or due(nst_log, step)) and step > step0:
             # potential terms at the final coordinates (mdrun evaluates one more force call than steps)
             _, e = eng.compute()
@@ -732,6 +758,9 @@ def mdrun(argv, out=sys.stdout, err=sys.stderr) -> int:
             if writer.error is not None:
                 raise writer.error
         wall = time.time() - t_loop0
+        prof["tail: all of it"] = time.perf_counter() - t_tail
+        if os.environ.get("MDX_RUNNER_TIMES"):
+            err.write("mdrun loop, seconds of the stepping thread: " + ", ".join("%s %.4f" % kv for kv in prof.items()) + "; wall %.4f\n" % wall)
         final_files(step)
         for w in (xtc, trr, px, pf, edr):
             if w is not None:
