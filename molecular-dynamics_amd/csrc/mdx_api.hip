@@ -770,6 +770,7 @@ extern "C" int mdx_compute_forces(mdx_system *s, unsigned terms)
 {
     (void)hipSetDevice(s->device);
     int rc;
+    s->bond_busy = true;        // (the bonded kernels below run on their own stream; a step that failed half-way may have left the flag down)
     if ((rc = mdx_launch_clear(s, true, true, true))) return rc;
     MDX_CHECK(s, hipMemsetAsync(s->f, 0, sizeof(float) * 3 * s->n, s->stream));
     if ((rc = mdx_search(s))) return rc;
