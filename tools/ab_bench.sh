@@ -2,7 +2,7 @@
 # A/B of engine switches on one box: bash tools/ab_bench.sh "label=KEYS" ... (KEYS as for MDX_DEBUG, "-" for none)
 for spec in "$@"; do
   label=${spec%%=*}; keys=${spec#*=}; [ "$keys" = "-" ] && keys=""
-  MDX_DEBUG="$keys" timeout -k 10 200 python bench.py --no-cpu-baseline --steps 3000 --warmup 300 > gpurun_out/ab_$label.json 2> gpurun_out/ab_$label.err || { tail -3 gpurun_out/ab_$label.err; exit 1; }
+  MDX_DEBUG="$keys" timeout -k 10 200 python bench.py --no-cpu-baseline --no-cli --steps 3000 --warmup 300 > gpurun_out/ab_$label.json 2> gpurun_out/ab_$label.err || { tail -3 gpurun_out/ab_$label.err; exit 1; }
   python - "$label" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/ab_%s.json" % sys.argv[1]))
