@@ -953,16 +953,16 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
         prepared = false;
         // Thermostat factors of the coupling period that the previous step ended: drawn on the bonded stream, which has just
         // been released behind that step's update; the join orders it ahead of this step's update, the first to use them.
-        // On a step without energies, pull or domain decomposition the bonded terms ride in the spreading launch; the bonded
+        // On a step without energies or domain decomposition the bonded terms (and the pull) ride in the spreading launch; the bonded
         // stream then carries this step's work only when the thermostat's factors or a trajectory frame are due.
-        const bool merge_bonded = phase == 0 && !need_vir && s->have_pme && !s->one_stream && !s->dd_on && !s->pull_on && !(s->dbg & 0x4000000);
+        const bool merge_bonded = phase == 0 && !need_vir && s->have_pme && !s->one_stream && !s->dd_on && !(s->dbg & 0x4000000);
         s->bond_busy = !merge_bonded || s->bond_carry;       // (bond_carry: the previous step left work there that this step's update needs)
         s->bond_carry = false;
         if (s->tc_fold_pending) { s->tc_fold_pending = false; s->bond_busy = true; if ((rc = mdx_launch_tcouple_fold(s, s->st_bond, s->tc_fold_step))) return rc; }
         // the nonbonded kernel is the critical path: enqueue it first, the side streams fill in
         if ((rc = mdx_launch_nonbonded(s, need_vir, MDX_F_NONBONDED | (s->have_pme ? MDX_F_EXCL : 0)))) return rc;
         if (phase == 0) {
-            if ((rc = mdx_launch_pme(s, need_vir, false, 0, merge_bonded ? (MDX_F_BONDED | MDX_F_POSRES) : 0u))) return rc;
+            if ((rc = mdx_launch_pme(s, need_vir, false, 0, merge_bonded ? (MDX_F_BONDED | MDX_F_POSRES | (s->pull_on ? MDX_F_PULL : 0u)) : 0u))) return rc;
         } else if (s->have_pme) {
             if (slabs) { if ((rc = mdx_launch_pme(s, false, false, 1))) return rc; }
             else if ((rc = mdx_launch_pme_spread(s, s->st_pme))) return rc;
@@ -972,7 +972,7 @@ static int step_phase(mdx_system *s, int phase, bool more, bool &forked_early, b
         // kinetic energy of the half step behind: reads only the velocities, which the update (behind the join) changes,
         // so it runs on the bonded stream beside the nonbonded kernel instead of ahead of it on the main stream
         if (need_vir) if ((rc = mdx_launch_ke(s, true, true, s->st_bond))) return rc;
-        if (s->pull_on) {
+        if (s->pull_on && !merge_bonded) {
             const bool log_now = (step % s->pull_nstout == 0);
             if ((rc = mdx_launch_pull(s, log_now, need_vir))) return rc;
         }

@@ -319,6 +319,8 @@ int mdx_launch_pme(mdx_system *s, bool energy, bool spread_done = false, int sta
 int mdx_launch_pme_spread(mdx_system *s, hipStream_t st, unsigned bonded_flags = 0);
 struct BondedArgs;
 void mdx_bonded_args(mdx_system *s, unsigned flags, BondedArgs &A);
+struct PullArgs;
+void mdx_pull_args(mdx_system *s, bool log_now, bool energy, PullArgs &P);
 int mdx_launch_bonded(mdx_system *s, bool energy, unsigned flags);
 int mdx_launch_pull(mdx_system *s, bool log_now, bool energy);
 int mdx_launch_update(mdx_system *s, bool do_tc, bool do_pr, bool virial);

@@ -5,6 +5,7 @@
 // triclinic dodecahedron needs no special casing; reciprocal vectors m = inv(box) . m'.
 #include "mdx_internal.h"
 #include "bonded_body.h"
+#include "pull_body.h"
 #include <hip/hip_ext.h>
 #include <algorithm>
 #include <cstdlib>
@@ -218,6 +219,21 @@ __global__ __launch_bounds__(256) void k_pme_spread_slab_bonded(SpreadSlabArgs A
     if ((int)blockIdx.y < brows) {
         const int b = blockIdx.y * gridDim.x + blockIdx.x;
         if (b < B.nblocks) bonded_block<false>(B, b, tile, (int *)(tile + 3 * MDX_BWIN));
+        return;
+    }
+    MDX_STAMP_ALL(d, 3);
+    spread_slab_block(A, d, (int)blockIdx.y - brows, tile);
+}
+
+// ... and with the centre-of-mass pull of the step as one more workgroup behind the bonded ones (a run with `pull = yes`).
+__global__ __launch_bounds__(256) void k_pme_spread_slab_bonded_pull(SpreadSlabArgs A, const DevState *__restrict__ d, BondedArgs B, int brows,
+                                                                     PullArgs P, const float4 *__restrict__ v, float *__restrict__ f, DevState *dw)
+{
+    extern __shared__ float tile[];
+    if ((int)blockIdx.y < brows) {
+        const int b = blockIdx.y * gridDim.x + blockIdx.x;
+        if (b < B.nblocks) bonded_block<false>(B, b, tile, (int *)(tile + 3 * MDX_BWIN));
+        else if (b == B.nblocks) pull_block(P, A.x, v, f, dw);
         return;
     }
     MDX_STAMP_ALL(d, 3);
@@ -884,7 +900,7 @@ void mdx_pme_free(mdx_system *s)
 }
 
 // Zero the charge grid (unless the last transform's x pass left it zeroed) and spread onto it, on stream `st`.
-// bonded_flags (MDX_F_BONDED | MDX_F_POSRES, or 0): the bonded terms of a step without energies ride in the same launch.
+// bonded_flags (MDX_F_BONDED | MDX_F_POSRES [| MDX_F_PULL], or 0): the bonded terms (and the pull) of a step without energies ride in the same launch.
 int mdx_launch_pme_spread(mdx_system *s, hipStream_t st, unsigned bonded_flags)
 {
     if (!s->have_pme) return MDX_OK;
@@ -917,7 +933,17 @@ int mdx_launch_pme_spread(mdx_system *s, hipStream_t st, unsigned bonded_flags)
     const int nq = ((s->ncx + B.qx - 1) / B.qx) * ((s->ncy + B.qy - 1) / B.qy);
     BondedArgs G; G.nblocks = 0;
     if (bonded_flags) mdx_bonded_args(s, bonded_flags, G);
-    if (G.nblocks > 0) {
+    const bool with_pull = (bonded_flags & MDX_F_PULL) && s->pull_on;
+    if (with_pull) {
+        // (the record of a logging step is counted here, as mdx_launch_pull does)
+        const bool log_now = s->step % s->pull_nstout == 0;
+        PullArgs P; mdx_pull_args(s, log_now, false, P);
+        const int brows = (G.nblocks + 1 + nq - 1) / nq;
+        ldss = std::max(ldss, sizeof(float) * 3 * MDX_BWIN + sizeof(int));
+        hipLaunchKernelGGL(k_pme_spread_slab_bonded_pull, dim3(nq, nslab + brows), dim3(256), ldss, st, B, (const DevState *)s->d, G, brows,
+                           P, (const float4 *)s->v, s->f, s->d);
+        if (log_now) s->pull_log_count++;
+    } else if (G.nblocks > 0) {
         const int brows = (G.nblocks + nq - 1) / nq;
         ldss = std::max(ldss, sizeof(float) * 3 * MDX_BWIN + sizeof(int));
         hipLaunchKernelGGL(k_pme_spread_slab_bonded, dim3(nq, nslab + brows), dim3(256), ldss, st, B, (const DevState *)s->d, G, brows);

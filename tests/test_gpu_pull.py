@@ -150,3 +150,30 @@ def test_groups_straddling_a_dodecahedron_face(small_complex, face):
     assert abs(o["r"] - o_intact["r"]) < 1e-6                       # the oracle itself is image invariant
     assert abs(rec[0, 1] - o_intact["r"]) < 3e-6
     assert _relrms(f.astype(np.float64), o_intact["forces"]) < FORCE_TOL
+
+
+def test_pull_in_the_spreading_launch_agrees_with_its_own_launch(small_complex):
+    """On steps without energies the pull rides in the charge-spreading launch (with the bonded terms); the same 30
+    steps with both kept in launches of their own on the bonded stream (mdx_debug_set key 2, bit 0x4000000): same
+    records, same trajectory up to the order of the float32 force sums, and the pull did move the ligand (a run
+    without the pull ends elsewhere)."""
+    s = small_complex
+    g1, g2 = s.groups["ActiveSite"], s.groups["MOL"]
+    out = []
+    for mode in ("merged", "separate", "no pull"):
+        e = _engine(s, seed=5)
+        if mode != "no pull":
+            e.set_pull(g1, g2, type="constant-force", k=5000.0, nstout=1)
+        if mode == "separate":
+            e.debug_set(2, 0x4000000)
+        for n in (1, 12, 17):
+            e.step(n)
+        x, _, _ = e.get_state()
+        rec = e.pop_pull_records() if mode != "no pull" else None
+        e.close()
+        out.append((x.astype(np.float64), rec))
+    (xa, ra), (xb, rb), (xc, _) = out
+    assert len(ra) == len(rb) == 30
+    assert np.abs(ra[:, 1] - rb[:, 1]).max() < 2e-6 and np.abs(ra[:, 3] - rb[:, 3]).max() < 1e-4 * np.abs(rb[:, 3]).max() + 1e-6
+    assert np.sqrt(((xa - xb) ** 2).sum(1).mean()) < 5e-6
+    assert np.abs(xa[g2] - xc[g2]).max() > 1e-4
