@@ -215,13 +215,13 @@ __global__ __launch_bounds__(256) void k_pme_spread_slab(SpreadSlabArgs A, const
 // (a wait for an event of another stream costs the main stream 2-3 us even when the event has long fired).
 __global__ __launch_bounds__(256) void k_pme_spread_slab_bonded(SpreadSlabArgs A, const DevState *__restrict__ d, BondedArgs B, int brows)
 {
+    MDX_STAMP_ALL(d, 3);      // (the launch as a whole, its bonded rows included)
     extern __shared__ float tile[];
     if ((int)blockIdx.y < brows) {
         const int b = blockIdx.y * gridDim.x + blockIdx.x;
         if (b < B.nblocks) bonded_block<false>(B, b, tile, (int *)(tile + 3 * MDX_BWIN));
         return;
     }
-    MDX_STAMP_ALL(d, 3);
     spread_slab_block(A, d, (int)blockIdx.y - brows, tile);
 }
 
@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256) void k_pme_spread_slab_bonded(SpreadSlabArgs A
 __global__ __launch_bounds__(256) void k_pme_spread_slab_bonded_pull(SpreadSlabArgs A, const DevState *__restrict__ d, BondedArgs B, int brows,
                                                                      PullArgs P, const float4 *__restrict__ v, float *__restrict__ f, DevState *dw)
 {
+    MDX_STAMP_ALL(d, 3);
     extern __shared__ float tile[];
     if ((int)blockIdx.y < brows) {
         const int b = blockIdx.y * gridDim.x + blockIdx.x;
@@ -236,7 +237,6 @@ __global__ __launch_bounds__(256) void k_pme_spread_slab_bonded_pull(SpreadSlabA
         else if (b == B.nblocks) pull_block(P, A.x, v, f, dw);
         return;
     }
-    MDX_STAMP_ALL(d, 3);
     spread_slab_block(A, d, (int)blockIdx.y - brows, tile);
 }
 
