@@ -12,7 +12,8 @@ extern "C" {
 
 /* Average time (ms) of `iters` back-to-back launches of the nonbonded kernel on the current pair list. */
 int mdx_debug_time_nonbonded(mdx_system *sys, int energy, int iters, double *avg_ms);
-/* Switches: key 2 diagnostic bits (0x400000 analytic nonbonded kernels instead of the tabulated ones, 512 library transform + stand-alone solve kernel, 0x2000000 y and z
+/* Switches: key 2 diagnostic bits (0x400000 analytic nonbonded kernels instead of the tabulated ones, 0x1000000 force kernel that combines the
+ * Lennard-Jones parameters per pair instead of reading them from the table by atom type, 512 library transform + stand-alone solve kernel, 0x2000000 y and z
  * transforms as separate launches, 0x4000000 bonded terms and pull always in launches of their own on the bonded stream, 0x8000000 pair search without the previous cluster order), 3 rounds of work units
  * handed out dynamically (0: static deal), 4 log2 of the parts a dynamically handed unit is cut into, 10 streams per
  * handle (1 or 3), 11 pair statistics on the energy steps of mdx_step, 12 fused update on or off, 14 list entries per

@@ -117,7 +117,7 @@ extern "C" mdx_system *mdx_create(int device, int natoms)
     s->excl_cap = (s->npad / 64) * 4 * MDX_EXCL_PER_WAVE + 1;
     auto A = [&](auto **p, size_t c) { ok = ok && (dev_alloc(s, p, c) == MDX_OK); };
     A(&s->x, n); A(&s->xp, n); A(&s->v, n); A(&s->f, 3 * (size_t)n); A(&s->f_pme, 3 * (size_t)n); A(&s->lj, n); A(&s->molid, n); A(&s->tcgrp, n);
-    A(&s->xq_s, s->npad); A(&s->lj_s, s->npad); A(&s->f_s, 3 * (size_t)s->npad); A(&s->perm, s->npad); A(&s->perm_src, s->npad);
+    A(&s->xq_s, s->npad); A(&s->lj_s, s->npad); A(&s->ljt_s, s->npad); A(&s->ljtype, n); A(&s->f_s, 3 * (size_t)s->npad); A(&s->perm, s->npad); A(&s->perm_src, s->npad);
     A(&s->shift_s, s->npad); A(&s->molid_s, s->npad); A(&s->sorted_of, n);
     A(&s->bb_lo, s->npad / 8); A(&s->bb_hi, s->npad / 8); A(&s->sbb_lo, s->npad / 64); A(&s->sbb_hi, s->npad / 64);
     A(&s->col_count, s->ncol_cap + 1); A(&s->col_astart, s->ncol_cap + 1); A(&s->col_scstart, s->ncol_cap + 1); A(&s->col_atoms, n);
@@ -152,7 +152,7 @@ extern "C" void mdx_destroy(mdx_system *s)
     (void)hipDeviceSynchronize();
     mdx_pme_free(s);
     mdx_frames_free(s);
-    void *ptrs[] = { s->x, s->xp, s->v, s->f, s->f_pme, s->lj, s->molid, s->tcgrp, s->excl_start, s->excl_list, s->excl_pairs, s->xq_s, s->lj_s,
+    void *ptrs[] = { s->ljtype, s->ljt_s, s->nbfp, s->x, s->xp, s->v, s->f, s->f_pme, s->lj, s->molid, s->tcgrp, s->excl_start, s->excl_list, s->excl_pairs, s->xq_s, s->lj_s,
                      s->f_s, s->perm, s->perm_src, s->shift_s, s->molid_s, s->sorted_of, s->bb_lo, s->bb_hi, s->sbb_lo, s->sbb_hi,
                      s->col_count, s->col_astart, s->col_scstart, s->col_atoms, s->atom_col, s->atom_slot, s->wrapped, s->cj, s->work, s->work_order, s->sc_nwork,
                      s->exclmask, s->shift_ijk, s->shiftvec, s->bond_ij, s->bond_p, s->angle_ijk, s->angle_p, s->dih_ijkl, s->dih_p,
@@ -210,6 +210,36 @@ extern "C" int mdx_set_atoms(mdx_system *s, const float *mass, const float *char
         if (tc_group) ARG_CHECK(s, tc_group[i] >= 0 && tc_group[i] < MDX_MAX_TC, "mdx_set_atoms: tc_group out of range");
     }
     MDX_CHECK(s, hipMemcpy(s->lj, lj.data(), sizeof(float2) * n, hipMemcpyHostToDevice));
+    {
+        // atom types of the force kernel: one per distinct (sigma, epsilon) with epsilon > 0, type 0 for atoms without a well
+        std::vector<std::pair<float, float>> types(1, std::make_pair(0.0f, 0.0f));
+        std::vector<int> ty(n);
+        for (int i = 0; i < n; i++) {
+            int t = 0;
+            if (epsilon[i] > 0.0f) {
+                const auto key = std::make_pair(sigma[i], epsilon[i]);
+                t = (int)(std::find(types.begin() + 1, types.end(), key) - types.begin());
+                if (t == (int)types.size()) types.push_back(key);
+            }
+            ty[i] = 8 * t;
+            if ((int)types.size() > MDX_NB_MAXTYPES) break;
+        }
+        if (s->nbfp) { (void)hipFree(s->nbfp); s->nbfp = nullptr; }
+        s->nt = (int)types.size() <= MDX_NB_MAXTYPES ? (int)types.size() : 0;
+        if (s->nt > 0) {
+            std::vector<float2> tab((size_t)s->nt * s->nt, make_float2(0.0f, 0.0f));
+            for (int a = 1; a < s->nt; a++)
+                for (int b = 1; b < s->nt; b++) {
+                    const double sg = 0.5 * ((double)types[a].first + types[b].first);
+                    const double e4 = 4.0 * sqrt((double)types[a].second * types[b].second);
+                    const double s6 = sg * sg * sg * sg * sg * sg;
+                    tab[(size_t)a * s->nt + b] = make_float2((float)(12.0 * e4 * s6 * s6), (float)(6.0 * e4 * s6));
+                }
+            MDX_CHECK(s, hipMalloc((void **)&s->nbfp, sizeof(float2) * tab.size()));
+            MDX_CHECK(s, hipMemcpy(s->nbfp, tab.data(), sizeof(float2) * tab.size(), hipMemcpyHostToDevice));
+            MDX_CHECK(s, hipMemcpy(s->ljtype, ty.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+        } else MDX_CHECK(s, hipMemset(s->ljtype, 0, sizeof(int) * n));
+    }
     MDX_CHECK(s, hipMemcpy(s->molid, molid, sizeof(int) * n, hipMemcpyHostToDevice));
     if (tc_group) MDX_CHECK(s, hipMemcpy(s->tcgrp, tc_group, sizeof(int) * n, hipMemcpyHostToDevice));
     return MDX_OK;

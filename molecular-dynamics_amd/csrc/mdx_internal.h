@@ -12,6 +12,7 @@
 #define MDX_MAX_TC 8
 #define MDX_MAX_SHIFTS 48
 #define MDX_NB_CHUNK 32          // j-clusters per nonbonded work unit
+#define MDX_NB_MAXTYPES 32       // Lennard-Jones atom types the force kernel's LDS table holds (type 0: no well)
 #define MDX_MAX_COL 2048         // atoms per grid column handled by the in-LDS sort
 #define MDX_GTAB_N 4096          // points of the tabulated Ewald correction used by the force-only nonbonded kernel
 #define MDX_LINCS_MAXK 16        // constraints per coupled component
@@ -154,6 +155,9 @@ struct mdx_system {
     // ---- sorted (cluster) layout
     float4 *xq_s = nullptr;       // npad
     float2 *lj_s = nullptr;
+    // Lennard-Jones by atom type (force kernel of the step loop): atoms with the same (sigma, epsilon) share a type, type 0 has no LJ;
+    // ljtype: 8 * type per atom, ljt_s: the same in cluster order, nbfp: nt x nt entries (12 C12, 6 C6); nt = 0: more types than the kernel's table holds
+    int *ljtype = nullptr, *ljt_s = nullptr; float2 *nbfp = nullptr; int nt = 0;
     float *f_s = nullptr;         // 3*npad
     int *perm = nullptr;          // sorted -> original (-1 filler)
     int *perm_src = nullptr;      // sorted -> original atom whose position is used (always valid)

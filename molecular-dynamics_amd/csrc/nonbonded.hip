@@ -37,6 +37,9 @@ struct NbArgs {
     int dyn_split;               // log2 of the parts a unit is cut into when handed out dynamically
     int dyn;                     // rounds' worth of units at the cheap end of the list handed out dynamically (0: static deal only)
     long long *wave_t;           // diagnostic: per wave (start clock, end clock, wall start, wall end, units, entries)
+    const int *ljt_s;            // typed force kernel: 8 * atom type per slot of the cluster order
+    const float2 *nbfp;          // ... nt x nt entries (12 C12, 6 C6)
+    int nt;
 };
 
 // Element `idx` of an array of at most 4 GB through a 32-bit byte offset: the access then takes the uniform base from
@@ -101,9 +104,10 @@ __device__ __forceinline__ float mdx_pmecorr(float w)
 // domains' atoms); a compile-time switch, because the handful of extra instructions per tile costs the energy kernel a
 // third of its speed (304 against 227 us) and a single-domain run never needs them.
 // TIMED: per-wave clocks and tile counters for mdx_debug_wave_times.
-template <bool ENERGY, int TAB, int NI = 8, bool WGT = false, bool COUNT = true, bool TIMED = false>
-__device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nullptr, float2 *ilj = nullptr)
+template <bool ENERGY, int TAB, int NI = 8, bool WGT = false, bool COUNT = true, bool TIMED = false, bool TYPED = false>
+__device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nullptr, float2 *ilj = nullptr, const float2 *ljtab = nullptr)
 {
+    static_assert(!TYPED || (!ENERGY && TAB == 1), "Lennard-Jones by type: the tabulated force kernel only");
     MDX_STAMP(A.dw, ENERGY ? 2 : 1);
     static_assert(TAB == 0 || TAB == (ENERGY ? 2 : 1), "force kernels take the float2 table, energy kernels the float4 table");
     constexpr bool ILDS = TAB != 0;
@@ -189,7 +193,8 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
         if (ILDS) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // the previous pass has read its values
         float fix[NI], fiy[NI], fiz[NI];
         // (one load and one LDS store per wave: lane l brings the pair of the l-th i-atom)
-        if (ILDS && lane < NI * 8) myilj[lane] = *at32(A.lj_s, (unsigned)((sci * 8 + c0) * 8 + lane));
+        if (TYPED) { if (lane < NI * 8) myilj[lane] = make_float2(__int_as_float(*at32(A.ljt_s, (unsigned)((sci * 8 + c0) * 8 + lane)) * A.nt), 0.0f); }      // byte offset of the i-atom's table row
+        else if (ILDS && lane < NI * 8) myilj[lane] = *at32(A.lj_s, (unsigned)((sci * 8 + c0) * 8 + lane));
 #pragma unroll
         for (int c = 0; c < NI; c++) {
             const int ia = (sci * 8 + c0 + c) * 8 + ti;
@@ -209,7 +214,8 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
         auto fetch = [&](JSet &J, const int e) {
             J.cj = __builtin_amdgcn_readlane(myent.cj, e);
             J.pj = *at32(A.xq_s, (unsigned)(J.cj * 8 + tj));
-            J.lj = *at32(A.lj_s, (unsigned)(J.cj * 8 + tj));
+            if (TYPED) J.lj = make_float2(__int_as_float(*at32(A.ljt_s, (unsigned)(J.cj * 8 + tj))), 0.0f);      // byte offset inside a table row
+            else J.lj = *at32(A.lj_s, (unsigned)(J.cj * 8 + tj));
             J.mk = (unsigned)__builtin_amdgcn_readlane((int)myent.mask, e);
             J.ex = 0xFFu;
             if (J.mk >> 8) J.ex = A.exclmask[(J.mk >> 8) * 64u + (unsigned)lane];
@@ -267,13 +273,22 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                         // integer may land in the interval below, whose line meets the next one there)
                         const float u = fmaf(r2, scale_v, 1048576.0f - 0.0625f);
                         const float2 te = *(const float2 *)((const char *)gtab + (__float_as_uint(u) & 0x7FF8u));
-                        const float2 li = myilj[c * 8 + ti];
-                        const float sg = li.x + lj.x;
-                        const float e4 = fabsf(li.y) * fabsf(lj.y);
-                        const float s2 = sg * sg * rinv2;
-                        const float s6 = s2 * s2 * s2;
-                        const float t6 = e4 * s6;
-                        float fs = t6 * fmaf(12.0f, s6, -6.0f);
+                        float fs;
+                        if (TYPED) {
+                            // (12 C12 r^-6 - 6 C6) r^-6 from the type pair's table entry: five instructions where combining
+                            // half-sigmas and well depths per pair takes nine
+                            const float2 cc = *(const float2 *)((const char *)ljtab + (__float_as_int(myilj[c * 8 + ti].x) + __float_as_int(lj.x)));
+                            const float rinv6 = rinv2 * rinv2 * rinv2;
+                            fs = rinv6 * fmaf(cc.x, rinv6, -cc.y);
+                        } else {
+                            const float2 li = myilj[c * 8 + ti];
+                            const float sg = li.x + lj.x;
+                            const float e4 = fabsf(li.y) * fabsf(lj.y);
+                            const float s2 = sg * sg * rinv2;
+                            const float s6 = s2 * s2 * s2;
+                            const float t6 = e4 * s6;
+                            fs = t6 * fmaf(12.0f, s6, -6.0f);
+                        }
                         const float qq = qi[c] * pj.w;
                         fs = fmaf(qq, rinv, fs) * rinv2;
                         const float g = fmaf(r2, te.y, te.x);
@@ -331,8 +346,9 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                 const bool listed = GENERAL ? (((exh >> c) & 1u) != 0u) : true;   // false: excluded pair, Ewald correction only
                 const float rinv = __frsqrt_rn(r2);
                 const float rinv2 = rinv * rinv;
-                float hs_c, se_c;
-                if (ILDS) { const float2 li = myilj[c * 8 + ti]; hs_c = li.x; se_c = li.y; } else { hs_c = hsi[c]; se_c = sei[c]; }
+                float hs_c = 0.0f, se_c = 0.0f;
+                if (TYPED) { }
+                else if (ILDS) { const float2 li = myilj[c * 8 + ti]; hs_c = li.x; se_c = li.y; } else { hs_c = hsi[c]; se_c = sei[c]; }
                 const float sg = hs_c + lj.x;
                 // (a negative sign on 2 sqrt(eps), zero included, marks an atom that another domain owns: domain decomposition)
                 const float e4 = fabsf(se_c) * fabsf(lj.y);
@@ -340,6 +356,11 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                 const float s6 = s2 * s2 * s2;
                 const float t6 = e4 * s6;
                 float fs = t6 * fmaf(12.0f, s6, -6.0f);
+                if (TYPED) {
+                    const float2 cc = *(const float2 *)((const char *)ljtab + (__float_as_int(myilj[c * 8 + ti].x) + __float_as_int(lj.x)));
+                    const float rinv6 = rinv2 * rinv2 * rinv2;
+                    fs = rinv6 * fmaf(cc.x, rinv6, -cc.y);
+                }
                 const float qq = qi[c] * pj.w;
                 float erfc_br = 0.0f, e_ex = 0.0f;
                 if (ENERGY && TAB == 2) {
@@ -532,7 +553,20 @@ __device__ __forceinline__ void nb_force_tab(const NbArgs &A)
     __syncthreads();
     nb_body<false, 1, 8, false, true, TIMED>(A, (const float2 *)tab4, ilj);
 }
+// ... with the Lennard-Jones parameters by atom type: a table of (12 C12, 6 C6) per type pair in LDS beside the Ewald table
+__device__ __forceinline__ void nb_force_tab_typed(const NbArgs &A)
+{
+    __shared__ float4 tab4[MDX_GTAB_N / 2];
+    __shared__ float2 ilj[12 * 64];
+    __shared__ float2 ljtab[MDX_NB_MAXTYPES * MDX_NB_MAXTYPES];
+    const float4 *src = (const float4 *)A.gtab;
+    for (int k = threadIdx.x; k < MDX_GTAB_N / 2; k += 768) tab4[k] = src[k];
+    for (int k = threadIdx.x; k < A.nt * A.nt; k += 768) ljtab[k] = A.nbfp[k];
+    __syncthreads();
+    nb_body<false, 1, 8, false, true, false, true>(A, (const float2 *)tab4, ilj, ljtab);
+}
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_f(NbArgs A) { nb_force_tab<false>(A); }
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_ft(NbArgs A) { nb_force_tab_typed(A); }
 // ... with per-wave clocks and tile counters (mdx_debug_wave_times)
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f_timed(NbArgs A) { nb_force_tab<true>(A); }
 // Energy/virial kernel with g and h tabulated (64 KB per CU): no exponential, no erfc polynomial. Four i-clusters at a
@@ -578,7 +612,7 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
         A.work = s->work_in[s->inner_cur]; A.cj = s->cj_in[s->inner_cur]; A.order = s->order_in[s->inner_cur];
         A.nwork = &s->d->nwork_in[s->inner_cur];
     }
-    A.exclmask = s->exclmask; A.xq_s = s->xq_s; A.lj_s = s->lj_s;
+    A.exclmask = s->exclmask; A.xq_s = s->xq_s; A.lj_s = s->lj_s; A.ljt_s = s->ljt_s; A.nbfp = s->nbfp; A.nt = s->nt;
     A.shiftvec = s->shiftvec; A.f_s = s->f_s;
     A.rc2 = s->rc * s->rc; A.beta = s->beta;
     A.c_rf_shift = (float)(erfc((double)s->beta * s->rc) / s->rc);
@@ -611,7 +645,7 @@ int mdx_launch_nonbonded(mdx_system *s, bool energy, unsigned terms)
     if (!tables) {
         kern = energy ? (s->dd_on ? k_nonbonded_ev_analytic_dd : k_nonbonded_ev_analytic) : k_nonbonded_f_analytic;
         grid = dim3(256 * 3); block = dim3(256);
-    } else if (!energy) kern = s->nb_wave_t ? k_nonbonded_f_timed : k_nonbonded_f;
+    } else if (!energy) kern = s->nb_wave_t ? k_nonbonded_f_timed : ((s->nt > 0 && !s->dd_on && !(s->dbg & 0x1000000)) ? k_nonbonded_ft : k_nonbonded_f);
     else if (s->dd_on) kern = k_nonbonded_ev_dd;
     else kern = s->count_pairs ? k_nonbonded_ev_count : k_nonbonded_ev;
     hipExtLaunchKernelGGL(kern, grid, block, 0, s->stream, ev_a, ev_b, 0, A);

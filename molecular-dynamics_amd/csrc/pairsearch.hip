@@ -167,7 +167,7 @@ __global__ __launch_bounds__(1024) void k_sortcol(int *__restrict__ col_count, c
                                                  int *__restrict__ perm_src, int *__restrict__ shift_s, int *__restrict__ molid_s,
                                                  int *__restrict__ sorted_of, float4 *__restrict__ bb_lo, float4 *__restrict__ bb_hi,
                                                  float4 *__restrict__ sbb_lo, float4 *__restrict__ sbb_hi, int nsc_cap,
-                                                 const float4 *__restrict__ v_home)
+                                                 const float4 *__restrict__ v_home, const int *__restrict__ ljtype, int *__restrict__ ljt_s)
 {
     __shared__ float kz[MDX_MAX_COL], ky[MDX_MAX_COL], kx[MDX_MAX_COL];
     __shared__ int id[MDX_MAX_COL];
@@ -213,6 +213,7 @@ __global__ __launch_bounds__(1024) void k_sortcol(int *__restrict__ col_count, c
         xq_s[g] = make_float4(w.x, w.y, w.z, q);
         // a filler carries no charge and no LJ well; the negative sign of its (negligible) half-sigma marks it for the pair counters
         lj_s[g] = filler ? make_float2(-1.0e-30f, 0.0f) : lj[as];
+        ljt_s[g] = filler ? 0 : ljtype[as];
         perm[g] = filler ? -1 : a;
         perm_src[g] = as;
         shift_s[g] = __float_as_int(w.w);
@@ -784,7 +785,7 @@ int mdx_search(mdx_system *s)
     hipLaunchKernelGGL(k_sortcol, dim3(ncol), dim3(1024), 0, s->stream, s->col_count, s->col_astart, s->col_scstart,
                        s->col_atoms, s->wrapped, s->x, s->lj, s->molid, s->xq_s, s->lj_s, s->perm, s->perm_src, s->shift_s,
                        s->molid_s, s->sorted_of, s->bb_lo, s->bb_hi, s->sbb_lo, s->sbb_hi, s->npad / 64,
-                       (const float4 *)(s->dd_on ? s->v : nullptr));
+                       (const float4 *)(s->dd_on ? s->v : nullptr), (const int *)s->ljtype, s->ljt_s);
     ListArgs A;
     A.dro = s->d; A.d = s->d; A.ncx = ncx; A.ncy = ncy; A.col_scstart = s->col_scstart; A.xq_s = s->xq_s; A.perm = s->perm;
     A.molid_s = s->molid_s; A.bb_lo = s->bb_lo; A.bb_hi = s->bb_hi; A.sbb_lo = s->sbb_lo; A.sbb_hi = s->sbb_hi;

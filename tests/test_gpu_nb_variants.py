@@ -40,3 +40,22 @@ def test_variants_agree(small_complex):
         assert np.abs(xa - xb).max() < 5e-4
     finally:
         e.close()
+
+
+def test_force_kernel_with_type_table_agrees_with_per_pair_combination(small_complex):
+    """The force-only kernel of the step loop takes (12 C12, 6 C6) of a pair from a table by atom type; mdx_debug_set key 2
+    bit 0x1000000 selects the kernel that combines half-sigmas and well depths per pair (also what a system with more
+    types than the table holds, and a decomposed run, get). One step from rest, so the new velocities are the forces."""
+    import copy
+    s = copy.copy(small_complex)
+    s.v = np.zeros_like(s.x)
+    out = []
+    for bit in (0, 0x1000000):
+        e = eng.Engine(s, rc=1.0, nstcalcenergy=0, dt=0.002)
+        e.debug_set(2, bit)
+        e.step(1)
+        _, v, _ = e.get_state()
+        out.append(v.astype(np.float64))
+        e.close()
+    assert relrms(out[0], out[1]) < 1e-5
+    assert np.abs(out[0]).max() > 1e-3

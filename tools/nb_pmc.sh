@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -o p -- python3 $R/tools/nb_pmc.py > $R/gpurun_out/pmc_$c.log 2>&1 || exit 1
   f=$(find $R/gpurun_out/pmc_$c -name "*counter_collection.csv" | tail -1)
-  python3 $R/tools/pmc_summary.py $f "k_nonbonded_f(" $c
+  python3 $R/tools/pmc_summary.py $f "k_nonbonded_ft(" $c
 done
 # summary for bench.py (FETCH_SIZE and WRITE_SIZE are in KB; gfx950 tallies this kernel's 16- and 8-byte per-lane loads at half size)
 cd $R
@@ -13,7 +13,7 @@ python3 - <<'PY'
 import csv, json, statistics, glob
 def med(c):
     f = sorted(glob.glob("gpurun_out/pmc_%s/*counter_collection.csv" % c))[-1]
-    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "k_nonbonded_f(" in r["Kernel_Name"] and r["Counter_Name"] == c]
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "k_nonbonded_ft(" in r["Kernel_Name"] and r["Counter_Name"] == c]
     return statistics.median(v), len(v)
 (fe, n), (wr, _) = med("FETCH_SIZE"), med("WRITE_SIZE")
 json.dump({"kernel": "k_nonbonded_f (force-only nonbonded, 12-wave workgroups, 3 waves/SIMD)",

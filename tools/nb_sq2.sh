@@ -2,7 +2,7 @@
 # Instruction mix and stall accounting of the force-only nonbonded kernel: three counter passes (GPU box, repository root).
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
-KERN=${KERN:-"k_nonbonded_f("}
+KERN=${KERN:-"k_nonbonded_ft("}
 pass() {
   tag=$1; shift
   timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_$tag -o p -- python3 $R/tools/nb_pmc.py > $R/gpurun_out/pmc_$tag.log 2>&1 || { tail -5 $R/gpurun_out/pmc_$tag.log; exit 1; }

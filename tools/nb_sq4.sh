@@ -2,7 +2,7 @@
 # Instruction and LDS accounting of a force-only nonbonded kernel (GPU box, repository root).
 # usage: tools/nb_sq4.sh KERNEL_NAME [MDX_DEBUG switches]
 R=$PWD
-K=${1:-"k_nonbonded_f("}
+K=${1:-"k_nonbonded_ft("}
 export MDX_DEBUG=$2
 cd /tmp && export TMPDIR=/tmp
 C="SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"
