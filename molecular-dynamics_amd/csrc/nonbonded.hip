@@ -185,6 +185,10 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
         if (PFV) { O4 = A.xq_s[sci * 64]; O4.x -= S.x; O4.y -= S.y; O4.z -= S.z; }
         NbEntry myent; myent.cj = 0; myent.mask = 0;
         if (lane < count) myent = A.cj[e0 + lane];
+        // (wave-uniform masks over the unit's entries, lane e for entry e)
+        const bool general_e = (myent.mask >> 8) != 0u || !do_pairs || (is_central && (myent.cj >> 3) == sci);
+        const unsigned long long general_bits = __builtin_amdgcn_ballot_w64(lane < count && general_e);
+        const unsigned long long plain_bits = __builtin_amdgcn_ballot_w64(lane < count && !general_e);
 #pragma unroll 1
         for (int half = 0; half < 8 / NI; half++) {
         const int c0 = half * NI;
@@ -220,7 +224,8 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
             J.ex = 0xFFu;
             if (J.mk >> 8) J.ex = A.exclmask[(J.mk >> 8) * 64u + (unsigned)lane];
         };
-        auto entry = [&](const JSet &J, const JSet &N) {
+        auto entry = [&](auto general_tag, const JSet &J, const JSet &N) {
+            constexpr bool general = decltype(general_tag)::value;
             const int cj = J.cj;
             const float4 pj = J.pj;
             const float2 lj = J.lj;
@@ -231,7 +236,6 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
             // `live` bit c: this lane's pair with i-cluster c is evaluated at all. In the tile of a
             // cluster with itself only tj > ti is (each pair once, no self pair); listed pairs need
             // do_pairs, excluded pairs need do_excl.
-            const bool general = slot != 0u || !do_pairs || (is_central && (cj >> 3) == sci);    // wave-uniform
             unsigned live = 0xFFu, exh = 0xFFu;
             if (general) {          // plain entries never look at these
                 live = do_pairs ? ex : 0u;
@@ -438,15 +442,9 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                     }
                 }
             };
-            if (!general) {
 #pragma unroll
-                for (int c = 0; c < NI; c++)
-                    if (imask & (1u << c)) tile(std::false_type{}, c);
-            } else {
-#pragma unroll
-                for (int c = 0; c < NI; c++)
-                    if (imask & (1u << c)) tile(std::true_type{}, c);
-            }
+            for (int c = 0; c < NI; c++)
+                if (imask & (1u << c)) tile(general_tag, c);
             // The wave waits for the next entry's j-atoms here, ahead of this entry's force atomics: memory operations
             // retire in order, so a wait placed behind the atomics (where the values are first used) would also wait for
             // the atomics to reach the L2, once per entry.
@@ -463,16 +461,29 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                 pvj[0] = fmaf(pj.x - O4.x, fm, pvj[0]); pvj[1] = fmaf(pj.y - O4.y, fm, pvj[1]); pvj[2] = fmaf(pj.z - O4.z, fm, pvj[2]);
             }
         };
-        JSet Ja, Jb;
-        fetch(Ja, 0);
-        Jb = Ja;
-        for (int e = 0; e < count; e += 2) {
-            if (e + 1 < count) fetch(Jb, e + 1);
-            entry(Ja, Jb);
-            if (e + 1 >= count) break;
-            if (e + 2 < count) fetch(Ja, e + 2);
-            entry(Jb, Ja);
-        }
+        // The entries whose tiles look at exclusion and liveness bits (a mask slot, a cluster with itself, a launch that
+        // leaves the listed pairs out) and the plain ones are walked in two loops of their own, the plain ones first: with
+        // both tile variants behind one branch in one loop the compiler keeps two registers per force sum of the i-atoms
+        // and copies one into the other on every tile that is skipped.
+        auto walk = [&](auto general_tag, unsigned long long bits) {
+            if (bits == 0ull) return;
+            JSet Ja, Jb;
+            fetch(Ja, __builtin_ctzll(bits));
+            bits &= bits - 1ull;
+            Jb = Ja;
+            for (;;) {
+                if (bits) fetch(Jb, __builtin_ctzll(bits));
+                entry(general_tag, Ja, Jb);
+                if (bits == 0ull) break;
+                bits &= bits - 1ull;
+                if (bits) fetch(Ja, __builtin_ctzll(bits));
+                entry(general_tag, Jb, Ja);
+                if (bits == 0ull) break;
+                bits &= bits - 1ull;
+            }
+        };
+        walk(std::false_type{}, plain_bits);
+        walk(std::true_type{}, general_bits);
 #pragma unroll
         for (int c = 0; c < NI; c++) {
             const float ax = fix[c], ay = fiy[c], az = fiz[c];
