@@ -197,8 +197,8 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
         if (ILDS) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // the previous pass has read its values
         float fix[NI], fiy[NI], fiz[NI];
         // (one load and one LDS store per wave: lane l brings the pair of the l-th i-atom)
-        if (TYPED) { if (lane < NI * 8) myilj[lane] = make_float2(__int_as_float(*at32(A.ljt_s, (unsigned)((sci * 8 + c0) * 8 + lane)) * A.nt), 0.0f); }      // byte offset of the i-atom's table row
-        else if (ILDS && lane < NI * 8) myilj[lane] = *at32(A.lj_s, (unsigned)((sci * 8 + c0) * 8 + lane));
+        int lio[TYPED ? NI : 1];         // TYPED: byte offset of the i-atom's row of the type-pair table
+        if (!TYPED && ILDS && lane < NI * 8) myilj[lane] = *at32(A.lj_s, (unsigned)((sci * 8 + c0) * 8 + lane));
 #pragma unroll
         for (int c = 0; c < NI; c++) {
             const int ia = (sci * 8 + c0 + c) * 8 + ti;
@@ -206,6 +206,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
             xi[c] = p.x - S.x; yi[c] = p.y - S.y; zi[c] = p.z - S.z;
             qi[c] = p.w * MDX_ONE_4PI_EPS0;
             if (!ILDS) { const float2 l = A.lj_s[ia]; hsi[c] = l.x; sei[c] = l.y; }
+            if (TYPED) lio[c] = *at32(A.ljt_s, (unsigned)ia) * A.nt;
             fix[c] = 0.0f; fiy[c] = 0.0f; fiz[c] = 0.0f;
         }
         // (LDS operations of one wave execute in order; the fence only keeps the compiler from moving the reads of
@@ -281,7 +282,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                         if (TYPED) {
                             // (12 C12 r^-6 - 6 C6) r^-6 from the type pair's table entry: five instructions where combining
                             // half-sigmas and well depths per pair takes nine
-                            const float2 cc = *(const float2 *)((const char *)ljtab + (__float_as_int(myilj[c * 8 + ti].x) + __float_as_int(lj.x)));
+                            const float2 cc = *(const float2 *)((const char *)ljtab + (lio[TYPED ? c : 0] + __float_as_int(lj.x)));
                             const float rinv6 = rinv2 * rinv2 * rinv2;
                             fs = rinv6 * fmaf(cc.x, rinv6, -cc.y);
                         } else {
@@ -361,7 +362,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
                 const float t6 = e4 * s6;
                 float fs = t6 * fmaf(12.0f, s6, -6.0f);
                 if (TYPED) {
-                    const float2 cc = *(const float2 *)((const char *)ljtab + (__float_as_int(myilj[c * 8 + ti].x) + __float_as_int(lj.x)));
+                    const float2 cc = *(const float2 *)((const char *)ljtab + (lio[TYPED ? c : 0] + __float_as_int(lj.x)));
                     const float rinv6 = rinv2 * rinv2 * rinv2;
                     fs = rinv6 * fmaf(cc.x, rinv6, -cc.y);
                 }
