@@ -79,13 +79,14 @@ struct MdxStamp {
     long long *mx;
     // first workgroup stamps the start, the last one (by index: about the last to be dispatched) the end; plain
     // stores, because thousands of workgroups updating one address would themselves stretch the kernel
-    // (all_end: every workgroup stamps the end, for a kernel whose last workgroups may be idle)
-    bool amax;
-    __device__ MdxStamp(const DevState *d, int id, bool all_end = false) {
+    // (all_end 1: every workgroup stamps the end, for a kernel whose last workgroups may be idle; 2: every wave, for a
+    // kernel whose waves draw work from queues and finish far apart)
+    __device__ MdxStamp(const DevState *d, int id, int all_end = 0) {
         DevState *w = const_cast<DevState *>(d);
-        mx = nullptr; amax = all_end;
+        mx = nullptr;
         if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) w->ts_min[id] = (long long)wall_clock64();
-        if (threadIdx.x == 0 && (all_end || (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1))) mx = &w->ts_max[id];
+        if ((threadIdx.x == 0 && (all_end || (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1))) ||
+            (all_end == 2 && (threadIdx.x & 63) == 0)) mx = &w->ts_max[id];
     }
     __device__ ~MdxStamp() {
         if (!mx) return;
@@ -95,10 +96,12 @@ struct MdxStamp {
     }
 };
 #define MDX_STAMP(d, id) MdxStamp stamp_((d), (id))
-#define MDX_STAMP_ALL(d, id) MdxStamp stamp_((d), (id), true)
+#define MDX_STAMP_ALL(d, id) MdxStamp stamp_((d), (id), 1)
+#define MDX_STAMP_WAVES(d, id) MdxStamp stamp_((d), (id), 2)
 #else
 #define MDX_STAMP(d, id)
 #define MDX_STAMP_ALL(d, id)
+#define MDX_STAMP_WAVES(d, id)
 #endif
 __device__ __forceinline__ int mdx_rep() { return (int)((blockIdx.x + 5u * blockIdx.y) & (MDX_NREP - 1)); }
 #define MDX_ENER(dw, t) ((dw)->ener_rep[mdx_rep()][t])

@@ -108,7 +108,7 @@ template <bool ENERGY, int TAB, int NI = 8, bool WGT = false, bool COUNT = true,
 __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nullptr, float2 *ilj = nullptr, const float2 *ljtab = nullptr)
 {
     static_assert(!TYPED || (!ENERGY && TAB == 1), "Lennard-Jones by type: the tabulated force kernel only");
-    MDX_STAMP(A.dw, ENERGY ? 2 : 1);
+    MDX_STAMP_WAVES(A.dw, ENERGY ? 2 : 1);
     static_assert(TAB == 0 || TAB == (ENERGY ? 2 : 1), "force kernels take the float2 table, energy kernels the float4 table");
     constexpr bool ILDS = TAB != 0;
     constexpr bool XM = !ENERGY && TAB == 1;      // execution-masked plain tile (see the tile below)
