@@ -99,7 +99,7 @@ __device__ __forceinline__ float mdx_pmecorr(float w)
 // h = erf(z)/z from a float4 table in LDS. With a table the LJ parameters of the i-atoms live in LDS too (`ilj`, 64
 // float2 per wave) instead of 16 registers.
 // NI: i-clusters of the super-cluster held in registers at a time; NI = 4 walks the unit's entries twice (36 registers
-// fewer, j-atoms loaded and j-forces reduced twice), so that waves of other kernels fit beside the energy kernel.
+// fewer, j-atoms loaded and j-forces reduced twice): the energy kernel of a decomposed run, whose pair weights need them.
 // WGT: pairs carry the weights 1, 1/2, 0 in energies and virial (a domain of a decomposed run: pairs with copies of other
 // domains' atoms); a compile-time switch, because the handful of extra instructions per tile costs the energy kernel a
 // third of its speed (304 against 227 us) and a single-domain run never needs them.
@@ -581,10 +581,11 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_ft(NbArgs A) { nb_force_tab_typed(A); }
 // ... with per-wave clocks and tile counters (mdx_debug_wave_times)
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_nonbonded_f_timed(NbArgs A) { nb_force_tab<true>(A); }
-// Energy/virial kernel with g and h tabulated (64 KB per CU): no exponential, no erfc polynomial. Four i-clusters at a
-// time (two passes over a unit's entries), which fits beside the kernels of the PME and bonded streams: all eight in one
-// pass (158 registers) is faster alone and no faster inside the step (1032-1047 against 1050 ns/day). COUNT adds the pair
-// statistics (mdx_compute_forces, and steps that ask for them); WGT the pair weights of a decomposed run.
+// Energy/virial kernel with g and h tabulated (64 KB per CU): no exponential, no erfc polynomial. All eight i-clusters
+// of a unit in one pass over its entries (127 registers; 128 us alone against 162 for two passes over four at a time,
+// which load the j-atoms and reduce the j-forces twice), except with the pair weights of a decomposed run, whose extra
+// registers do not fit a single pass. COUNT adds the pair statistics (mdx_compute_forces, and steps that ask for them);
+// WGT the pair weights of a decomposed run.
 template <int NI, bool WGT, bool COUNT>
 __device__ __forceinline__ void nb_energy_tab(const NbArgs &A)
 {
@@ -598,8 +599,8 @@ __device__ __forceinline__ void nb_energy_tab(const NbArgs &A)
 // (waves_per_eu(3, 4), not (3, 3): an upper bound of three waves makes the compiler pad the register allocation past 128 so that a
 // fourth wave cannot fit, 136 per wave, and the 104 registers that leaves a SIMD do not hold the two waves per SIMD of a PME
 // plane workgroup: beside the energy kernel the whole PME chain then waited for nonbonded workgroups to retire)
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_nonbonded_ev(NbArgs A) { nb_energy_tab<4, false, false>(A); }
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_nonbonded_ev_count(NbArgs A) { nb_energy_tab<4, false, true>(A); }
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_nonbonded_ev(NbArgs A) { nb_energy_tab<8, false, false>(A); }
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_nonbonded_ev_count(NbArgs A) { nb_energy_tab<8, false, true>(A); }
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_nonbonded_ev_dd(NbArgs A) { nb_energy_tab<4, true, true>(A); }
 // Analytic kernels (rational Ewald correction, exp + erfc polynomial in the energy kernel): what a handle without Ewald
 // tables runs, and the cross-check of the tabulated kernels (mdx_debug_set key 2 bit 0x400000).
