@@ -685,6 +685,12 @@ template <bool ENERGY, bool BIG>
 __device__ __forceinline__ void yz_plane(const FftYzArgs &A)
 {
     MDX_STAMP(A.d, 5);
+    // One workgroup per k_x plane: a few dozen workgroups, each a serial chain of passes over its plane, on as many CUs
+    // beside the nonbonded kernel, and the longest link but one of the PME chain. Through the forward passes and the
+    // influence function its waves issue ahead of the other kernels' waves on their CU (20 instead of 29 us beside the
+    // nonbonded kernel, which loses 3 us on those CUs: +1.2 % on the step). The same in the PME kernels that cover all
+    // CUs holds the nonbonded kernel back everywhere (96 -> 115 us) and costs 8 %.
+    __builtin_amdgcn_s_setprio(3);
     extern __shared__ float2 fsm[];
     const int K1 = A.K1, K2 = A.K2, ps = K1 + 1;
     float2 *Wy = fsm, *Wz = Wy + K1, *P = Wz + K2;         // P[z * ps + y]
@@ -748,6 +754,7 @@ __device__ __forceinline__ void yz_plane(const FftYzArgs &A)
         }
         __syncthreads();
     }
+    __builtin_amdgcn_s_setprio(0);
     yz_lines<true, BIG>(P, Wz, K2, A.N1z, A.N2z, K1, 1, ps);
     yz_lines<true, BIG>(P, Wy, K1, A.N1y, A.N2y, K2, ps, 1);
     for (int idx = threadIdx.x; idx < K1 * K2; idx += blockDim.x) {
