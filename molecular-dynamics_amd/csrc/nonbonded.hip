@@ -46,6 +46,9 @@ struct NbArgs {
 // scalar registers and one lane offset register, with no 64-bit address arithmetic on the vector unit.
 template <class T> __device__ __forceinline__ T *at32(T *base, unsigned idx) { return (T *)((char *)base + idx * (unsigned)sizeof(T)); }
 template <class T> __device__ __forceinline__ const T *at32(const T *base, unsigned idx) { return (const T *)((const char *)base + idx * (unsigned)sizeof(T)); }
+// ... with the offset in bytes: a wave-uniform part (scalar unit) plus a lane part that never changes is one vector add
+template <class T> __device__ __forceinline__ T *atb(T *base, unsigned bytes) { return (T *)((char *)base + bytes); }
+template <class T> __device__ __forceinline__ const T *atb(const T *base, unsigned bytes) { return (const T *)((const char *)base + bytes); }
 
 // Cross-lane adds inside groups of 8 consecutive lanes as DPP moves (no LDS crossbar traffic).
 __device__ __forceinline__ float dpp_quad_x1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)); }
@@ -122,6 +125,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
     if (TIMED) { t_start = clock64(); w_start = wall_clock64(); }
     const int lane = threadIdx.x & 63;
     const int ti = lane & 7, tj = lane >> 3;
+    const unsigned tj16 = 16u * tj, tj4 = 4u * tj, fj_off = 4u * (3 * tj + ti);       // the lane's byte offsets inside a j-cluster: coordinates, parameters, forces
     const int nwork = *A.nwork;
     const int wpb = blockDim.x >> 6;          // waves per workgroup
     const int nwaves = gridDim.x * wpb;
@@ -218,9 +222,9 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
         struct JSet { int cj; float4 pj; float2 lj; unsigned mk; unsigned ex; };
         auto fetch = [&](JSet &J, const int e) {
             J.cj = __builtin_amdgcn_readlane(myent.cj, e);
-            J.pj = *at32(A.xq_s, (unsigned)(J.cj * 8 + tj));
-            if (TYPED) J.lj = make_float2(__int_as_float(*at32(A.ljt_s, (unsigned)(J.cj * 8 + tj))), 0.0f);      // byte offset inside a table row
-            else J.lj = *at32(A.lj_s, (unsigned)(J.cj * 8 + tj));
+            J.pj = *atb(A.xq_s, (unsigned)J.cj * 128u + tj16);
+            if (TYPED) J.lj = make_float2(__int_as_float(*atb(A.ljt_s, (unsigned)J.cj * 32u + tj4)), 0.0f);      // byte offset inside a table row
+            else J.lj = *atb(A.lj_s, (unsigned)J.cj * 64u + 2u * tj4);
             J.mk = (unsigned)__builtin_amdgcn_readlane((int)myent.mask, e);
             J.ex = 0xFFu;
             if (J.mk >> 8) J.ex = A.exclmask[(J.mk >> 8) * 64u + (unsigned)lane];
@@ -455,7 +459,7 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
             if (did) fj3 = sum8_xyz(fjx, fjy, fjz, (ti & 1) != 0, (ti & 2) != 0);
             // (one 24-lane atomic per entry: pairing two entries into one 48-lane atomic costs more VALU instructions in
             // the selects than the second atomic costs now that no wait sits behind it)
-            if (did && ti < 3) atomicAdd(at32(A.f_s, (unsigned)(3 * (cj * 8 + tj) + ti)), fj3);
+            if (did && ti < 3) atomicAdd(atb(A.f_s, (unsigned)cj * 96u + fj_off), fj3);
             if (PFV && did) {
                 // lanes ti < 3 hold component ti of the force on j-atom tj
                 const float fm = ti < 3 ? fj3 : 0.0f;
