@@ -220,14 +220,15 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
         // sets used in turn (the loop is unrolled by two by hand, so that no set is copied into the other).
         // (unsigned element indices: a uniform base plus a zero-extended 32-bit lane offset needs no 64-bit address arithmetic)
         struct JSet { int cj; float4 pj; float2 lj; unsigned mk; unsigned ex; };
-        auto fetch = [&](JSet &J, const int e) {
+        auto fetch = [&](auto general_tag, JSet &J, const int e) {
             J.cj = __builtin_amdgcn_readlane(myent.cj, e);
             J.pj = *atb(A.xq_s, (unsigned)J.cj * 128u + tj16);
             if (TYPED) J.lj = make_float2(__int_as_float(*atb(A.ljt_s, (unsigned)J.cj * 32u + tj4)), 0.0f);      // byte offset inside a table row
             else J.lj = *atb(A.lj_s, (unsigned)J.cj * 64u + 2u * tj4);
             J.mk = (unsigned)__builtin_amdgcn_readlane((int)myent.mask, e);
             J.ex = 0xFFu;
-            if (J.mk >> 8) J.ex = A.exclmask[(J.mk >> 8) * 64u + (unsigned)lane];
+            // (plain entries have no mask slot and never look at the exclusion bits)
+            if (decltype(general_tag)::value && (J.mk >> 8)) J.ex = A.exclmask[(J.mk >> 8) * 64u + (unsigned)lane];
         };
         auto entry = [&](auto general_tag, const JSet &J, const JSet &N) {
             constexpr bool general = decltype(general_tag)::value;
@@ -473,15 +474,15 @@ __device__ __forceinline__ void nb_body(const NbArgs &A, const float2 *gtab = nu
         auto walk = [&](auto general_tag, unsigned long long bits) {
             if (bits == 0ull) return;
             JSet Ja, Jb;
-            fetch(Ja, __builtin_ctzll(bits));
+            fetch(general_tag, Ja, __builtin_ctzll(bits));
             bits &= bits - 1ull;
             Jb = Ja;
             for (;;) {
-                if (bits) fetch(Jb, __builtin_ctzll(bits));
+                if (bits) fetch(general_tag, Jb, __builtin_ctzll(bits));
                 entry(general_tag, Ja, Jb);
                 if (bits == 0ull) break;
                 bits &= bits - 1ull;
-                if (bits) fetch(Ja, __builtin_ctzll(bits));
+                if (bits) fetch(general_tag, Ja, __builtin_ctzll(bits));
                 entry(general_tag, Jb, Ja);
                 if (bits == 0ull) break;
                 bits &= bits - 1ull;
@@ -600,11 +601,13 @@ __device__ __forceinline__ void nb_energy_tab(const NbArgs &A)
     __syncthreads();
     nb_body<true, 2, NI, WGT, COUNT>(A, (const float2 *)tab4, ilj);
 }
-// (waves_per_eu(3, 4), not (3, 3): an upper bound of three waves makes the compiler pad the register allocation past 128 so that a
-// fourth wave cannot fit, 136 per wave, and the 104 registers that leaves a SIMD do not hold the two waves per SIMD of a PME
-// plane workgroup: beside the energy kernel the whole PME chain then waited for nonbonded workgroups to retire)
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_nonbonded_ev(NbArgs A) { nb_energy_tab<8, false, false>(A); }
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_nonbonded_ev_count(NbArgs A) { nb_energy_tab<8, false, true>(A); }
+// (waves_per_eu(4, 4): at most 128 registers, like the force kernel. Three waves of more than 128 registers leave a SIMD too
+// little for the two 64-register waves per SIMD of a PME plane workgroup, and beside such an energy kernel the whole PME chain
+// waits for nonbonded workgroups to retire: with a bound of (3, 4) the one-pass kernel took 138 registers after an unrelated
+// change, ran 123 instead of 152 us, and made an energy step 55 us longer. A bound of (3, 3) pads any allocation past 128.
+// The two-pass kernel of a decomposed run needs fewer than 128 under either bound.)
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_ev(NbArgs A) { nb_energy_tab<8, false, false>(A); }
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nonbonded_ev_count(NbArgs A) { nb_energy_tab<8, false, true>(A); }
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_nonbonded_ev_dd(NbArgs A) { nb_energy_tab<4, true, true>(A); }
 // Analytic kernels (rational Ewald correction, exp + erfc polynomial in the energy kernel): what a handle without Ewald
 // tables runs, and the cross-check of the tabulated kernels (mdx_debug_set key 2 bit 0x400000).
