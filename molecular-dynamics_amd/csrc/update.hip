@@ -277,7 +277,10 @@ struct ConstrainArgs {
     int ncomp_small, ncomp; const int *comp_start; const int2 *cij; const float *clen; int order, niter;
     const float4 *x; float4 *xp; float4 *v; float inv_dt; DevState *dw;
 };
-template <bool VIRIAL>
+// LARGE: the launch has a range of components of more than 4 constraints, whose 16 x 16 coupling matrix per thread sets
+// the register allocation (168, with scratch memory) of every workgroup of the launch, the waters' included; a topology
+// constrained on bonds to hydrogens only has none and takes the kernel without that range.
+template <bool VIRIAL, bool LARGE>
 __global__ __launch_bounds__(128) void k_constrain(ConstrainArgs A)
 {
     MDX_STAMP(A.dw, 12);
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(128) void k_constrain(ConstrainArgs A)
     if (b < A.nbw) d_settle<VIRIAL>(b * 128 + threadIdx.x, A.nw, A.settle_idx, A.x, A.xp, A.v, A.doh, A.dhh, A.inv_dt, A.dw);
     else if (b < A.nbw + A.nb4)
         d_lincs<VIRIAL, 4>((b - A.nbw) * 128 + threadIdx.x, 0, A.ncomp_small, A.comp_start, A.cij, A.clen, A.x, A.xp, A.v, A.order, A.niter, A.inv_dt, A.dw);
-    else
+    else if (LARGE)
         d_lincs<VIRIAL, MDX_LINCS_MAXK>(A.ncomp_small + (b - A.nbw - A.nb4) * 128 + threadIdx.x, A.ncomp_small, A.ncomp - A.ncomp_small,
                                         A.comp_start, A.cij, A.clen, A.x, A.xp, A.v, A.order, A.niter, A.inv_dt, A.dw);
 }
@@ -926,8 +929,9 @@ int mdx_launch_constrain(mdx_system *s, float inv_dt, bool virial, int lincs_ite
         ConstrainArgs A;
         constrain_args(s, A, inv_dt, lincs_iter);
         const int nb16 = (s->ncomp - s->ncomp_small + 127) / 128;
-        if (virial) hipLaunchKernelGGL(k_constrain<true>, dim3(A.nbw + A.nb4 + nb16), dim3(128), 0, s->stream, A);
-        else hipLaunchKernelGGL(k_constrain<false>, dim3(A.nbw + A.nb4 + nb16), dim3(128), 0, s->stream, A);
+        void (*kern)(ConstrainArgs) = nb16 > 0 ? (virial ? k_constrain<true, true> : k_constrain<false, true>)
+                                               : (virial ? k_constrain<true, false> : k_constrain<false, false>);
+        hipLaunchKernelGGL(kern, dim3(A.nbw + A.nb4 + nb16), dim3(128), 0, s->stream, A);
         MDX_CHECK(s, hipGetLastError());
         return MDX_OK;
     }

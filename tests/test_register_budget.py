@@ -85,3 +85,7 @@ def test_kernels_that_share_a_simd_keep_their_register_budget():
     # fused update of a topology without large constraint components: four waves per SIMD, nothing in scratch memory
     for k, (vgpr, scratch) in find("k_update_fusedILb0ELb0EE").items():
         assert vgpr <= 104 and scratch == 0, (k, vgpr, scratch)
+    # constraint launch of the energy steps, same topologies: nothing in scratch memory
+    for pat in ("k_constrainILb0ELb0EE", "k_constrainILb1ELb0EE"):
+        for k, (vgpr, scratch) in find(pat).items():
+            assert vgpr <= 128 and scratch == 0, (k, vgpr, scratch)
