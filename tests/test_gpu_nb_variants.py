@@ -59,3 +59,21 @@ def test_force_kernel_with_type_table_agrees_with_per_pair_combination(small_com
         e.close()
     assert relrms(out[0], out[1]) < 1e-5
     assert np.abs(out[0]).max() > 1e-3
+
+
+def test_force_only_kernel_agrees_with_the_energy_kernel(small_complex):
+    """The step loop's force-only kernel (plain and general list entries walked in two loops of their own, Lennard-Jones by
+    type table) against the energy kernel, which test_gpu_parity.py checks against the oracle: one step from rest with and
+    without energies on that step, so the new velocities are the forces of the two kernels behind identical updates."""
+    import copy
+    s = copy.copy(small_complex)
+    s.v = np.zeros_like(s.x)
+    out = []
+    for nstcalc in (0, 1):
+        e = eng.Engine(s, rc=1.0, nstcalcenergy=nstcalc, dt=0.002)
+        e.step(1)
+        _, v, _ = e.get_state()
+        out.append(v.astype(np.float64))
+        e.close()
+    assert relrms(out[0], out[1]) < 1e-5
+    assert np.abs(out[0]).max() > 1e-3
